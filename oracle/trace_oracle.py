@@ -1,0 +1,218 @@
+"""
+TEST INFRASTRUCTURE ONLY -- CPU oracle for the sequential ray-trace hot path.
+
+This module is a CPU restatement (eager PyTorch, autograd-recorded backward) of the
+algorithm in the reference `torchlens/ray_tracing_lite.py`.  It exists so that the HIP
+kernels in `torchoptics_amd/csrc/` can be checked value-for-value; it is NOT part of the
+product.  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` may import it.  The product (`torchoptics_amd`) never imports it and fails
+loudly when its HIP library is missing.
+
+Pinning: `tests/golden/make_golden.py` ran the reference itself (imported from
+/root/reference in the build container) and committed its outputs as fixtures under
+`tests/golden/`; `tests/test_oracle_golden.py` checks this file against them (forward
+bit-exact in fp32, gradients equal).  The spherical path is therefore pinned by the
+reference.  The aspheric / Newton / OPD path (`trace_skew_general`) is an extension the
+reference does not have: PARITY UNPINNED by the reference for that part -- it is the
+definition the kernels are tested against.
+
+Reference map (file = torchlens/ray_tracing_lite.py):
+  sphere_hit        <- find_marching_distance_spherical  :525-545
+  advance           <- update_ray_coordinates            :514-522
+  retire_dead       <- reset_bad_rays (normalize=False)  :574-591
+  refract_sphere    <- apply_snell_spherical             :548-571
+  trace_skew        <- trace_skew                        :594-675
+  compute_rms2d     <- compute_rms2d                     :678-702
+The fp32 operation ORDER follows SURVEY.md Appendix A so that the forward is bit-exact
+with the reference on CPU.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+EPS = 1e-6          # ray_tracing_lite.py:530,552
+ACOS_EPS = 1e-7     # ray_tracing_lite.py:644
+
+
+@dataclass
+class RayBundle:
+    """Structure-of-arrays ray state in the local frame of the next surface vertex."""
+    x: torch.Tensor
+    y: torch.Tensor
+    z: torch.Tensor
+    cx: torch.Tensor
+    cy: torch.Tensor
+    cz: torch.Tensor
+    ok: torch.Tensor      # sticky "still alive" flag
+    back: torch.Tensor    # "travelled backwards somewhere" flag
+
+
+def sphere_hit(c: torch.Tensor, r: RayBundle):
+    """Closed-form ray/sphere marching distance (ref :525-545).
+
+    Returns (miss, d, cos_i, cos2_i).  cos_i is sqrt of a value forced to 1 where the
+    ray misses, which cuts the gradient for missed rays exactly as the reference does.
+    """
+    e = -(r.x * r.cx + r.y * r.cy + r.z * r.cz)
+    mz = r.z + e * r.cz
+    m2 = r.x ** 2 + r.y ** 2 + r.z ** 2 - e ** 2
+    tmp = c * m2 - 2 * mz
+    cos2_i = r.cz ** 2 - c * tmp
+    miss = cos2_i - EPS < 0
+    cos_i = torch.sqrt(torch.where(miss, torch.ones_like(cos2_i), cos2_i))
+    d = e + tmp / (r.cz + cos_i)
+    return miss, d, cos_i, cos2_i
+
+
+def advance(r: RayBundle, d: torch.Tensor) -> torch.Tensor:
+    """Move the bundle along its direction by d (ref :514-522); returns delta-z."""
+    dz = d * r.cz
+    r.x = r.x + d * r.cx
+    r.y = r.y + d * r.cy
+    r.z = r.z + dz
+    return dz
+
+
+def retire_dead(r: RayBundle) -> None:
+    """Dead rays are parked at the vertex pointing along +z (ref :574-591)."""
+    zero = torch.zeros((), dtype=r.x.dtype, device=r.x.device)
+    one = torch.ones((), dtype=r.x.dtype, device=r.x.device)
+    r.x = torch.where(r.ok, r.x, zero)
+    r.y = torch.where(r.ok, r.y, zero)
+    r.z = torch.where(r.ok, r.z, zero)
+    r.cx = torch.where(r.ok, r.cx, zero)
+    r.cy = torch.where(r.ok, r.cy, zero)
+    r.cz = torch.where(r.ok, r.cz, one)
+
+
+def refract_sphere(c: torch.Tensor, mu: torch.Tensor, r: RayBundle, cos_i: torch.Tensor):
+    """Snell refraction at a spherical interface (ref :548-571).
+
+    Updates r.cx, r.cy, r.cz; returns (fail, cos2_t).
+    """
+    cos2_t = 1 - mu ** 2 * (1 - cos_i ** 2)
+    tir = cos2_t - EPS < 0
+    cos_t = torch.sqrt(torch.where(tir, torch.ones_like(cos2_t), cos2_t))
+    g = cos_t - mu * cos_i
+    ncx = mu * r.cx - g * c * r.x
+    ncy = mu * r.cy - g * c * r.y
+    cz2 = 1 - (ncx ** 2 + ncy ** 2)
+    fail = tir | (cz2 - EPS < 0)
+    r.cx, r.cy = ncx, ncy
+    r.cz = torch.sqrt(torch.where(fail, torch.ones_like(cz2), cz2))
+    return fail, cos2_t
+
+
+def _flag_backward(r: RayBundle, dz: torch.Tensor, live: torch.Tensor, allow: bool) -> None:
+    """Backward-travel bookkeeping (ref :626-632, :665-670)."""
+    hit = (dz < 0) & live
+    if allow:
+        r.back = r.back | hit
+    else:
+        r.ok = r.ok & ~hit
+
+
+def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate: bool = False,
+               allow_backward_rays: bool = True):
+    """Sequential trace through S spherical surfaces to the image plane (ref :594-675).
+
+    Shapes as in the reference: x,y [1|B,1|F,P,1|W]; z [B,1,1,1]; cx [1,1,1,1];
+    cy [B,F,1,1]; c,t [B,1,1,1,S]; mu [B,1,1,W,S]; mask [B,1,1,1,S] (bool).
+    Returns (x, y, cx, cy, ray_ok, ray_backward[, stacks]).
+    """
+    n_surf = t.shape[-1]
+    cs, ts, mus, masks = (torch.unbind(a, dim=-1) for a in (c, t, mu, mask))
+
+    r = RayBundle(x, y, z, cx, cy, torch.sqrt(1 - cx ** 2 - cy ** 2),
+                  torch.ones_like(y, dtype=torch.bool), torch.zeros_like(y, dtype=torch.bool))
+    stacks: Dict[str, List[torch.Tensor]] = {'z_RELU': [], 'theta_norm': [], 'theta_prime_norm': []}
+    n_wave = mus[0].shape[-1]
+
+    for k in range(n_surf):
+        miss, d, cos_i, cos2_i = sphere_hit(cs[k], r)
+        dz = advance(r, d)
+        r.ok = r.ok & ~miss
+        retire_dead(r)
+        fail, cos2_t = refract_sphere(cs[k], mus[k], r, cos_i)
+        if k > 0:
+            _flag_backward(r, dz, r.ok & masks[k - 1], allow_backward_rays)
+        r.ok = r.ok & ~fail
+        retire_dead(r)
+        r.z = r.z - ts[k]
+
+        if aggregate:   # ref :641-657 (penalty-term raw material)
+            full = (*r.x.shape[:3], n_wave)
+            z_relu = torch.where(r.z <= 0, torch.zeros_like(r.z), r.z)
+            lo, hi = -1.0 + ACOS_EPS, 1.0 - ACOS_EPS
+            th_i = torch.acos(torch.clamp(torch.sqrt(cos2_i), min=lo, max=hi)) / (1 / 2 * math.pi)
+            th_t = torch.acos(torch.clamp(torch.sqrt(cos2_t), min=lo, max=hi)) / (1 / 2 * math.pi)
+            # the reference indexes theta[~ray_ok] in place, which only works when the
+            # shapes already agree; broadcast first, same values.
+            ok_b = torch.broadcast_to(r.ok, full)
+            one = torch.ones((), dtype=th_i.dtype, device=th_i.device)
+            th_i = torch.where(ok_b, torch.broadcast_to(th_i, full), one)
+            th_t = torch.where(ok_b, torch.broadcast_to(th_t, full), one)
+            stacks['z_RELU'].append(torch.broadcast_to(z_relu, full))
+            stacks['theta_norm'].append(th_i)
+            stacks['theta_prime_norm'].append(th_t)
+
+    # transfer to the image plane (ref :659-663)
+    dz = -r.z
+    dist = dz / r.cz
+    r.x = r.x + dist * r.cx
+    r.y = r.y + dist * r.cy
+    _flag_backward(r, dz, r.ok & masks[-1], allow_backward_rays)
+
+    if aggregate:
+        return r.x, r.y, r.cx, r.cy, r.ok, r.back, stacks
+    return r.x, r.y, r.cx, r.cy, r.ok, r.back
+
+
+def compute_rms2d(x, y, ray_ok):
+    """y-only RMS spot for sample 0, averaged over fields (ref :678-702).
+
+    Per field: centroid = mean over wavelengths of the mean over ALL pupil points
+    (failed rays sit at y=0 and are counted); numerator sums only live rays; the
+    denominator is P*W regardless.  `x` is accepted and ignored, as in the reference.
+    """
+    n_f, n_p, n_w = y.shape[1], y.shape[2], y.shape[3]
+    total = 0.
+    for yf, okf in zip(torch.unbind(y[0], dim=0), torch.unbind(ray_ok[0], dim=0)):
+        cen = 0.
+        for w in range(n_w):
+            cen = cen + torch.mean(yf[:, w])
+        cen = cen / n_w
+        total = total + torch.sqrt(torch.sum((yf[okf] - cen) ** 2) / (n_p * n_w))
+    return total / n_f
+
+
+# ----------------------------------------------------------------------------------
+# Closed forms used by the sharded (multi-GPU) path; checked against compute_rms2d.
+# ----------------------------------------------------------------------------------
+
+def spot_moments(y: torch.Tensor, ray_ok: torch.Tensor) -> torch.Tensor:
+    """Per-field fp64 moments [F,4] = (sum y, sum ok*y, sum ok*y^2, sum ok) of sample 0."""
+    yd = y[0].double()
+    okd = ray_ok[0].double()
+    return torch.stack((yd.sum(dim=(1, 2)), (okd * yd).sum(dim=(1, 2)),
+                        (okd * yd * yd).sum(dim=(1, 2)), okd.sum(dim=(1, 2))), dim=1)
+
+
+def rms_from_moments(m: torch.Tensor, n_per_field: int) -> torch.Tensor:
+    """compute_rms2d rewritten on the four moments; fp64 in, fp64 out."""
+    mean = m[:, 0] / n_per_field
+    var = (m[:, 2] - 2 * mean * m[:, 1] + mean * mean * m[:, 3]) / n_per_field
+    return torch.sqrt(var).mean()
+
+
+def penalty_from_stacks(stacks, n_sequence: int) -> torch.Tensor:
+    """sum over rays of Q (reference optics_simulator_lite.py:441-448)."""
+    q = (torch.stack(stacks['theta_norm'], dim=0).sum(dim=0)
+         + torch.stack(stacks['theta_prime_norm'], dim=0).sum(dim=0)
+         + torch.stack(stacks['z_RELU'], dim=0).sum(dim=0)) / n_sequence
+    q = torch.where(torch.isnan(q), torch.zeros_like(q), q)
+    return torch.sum(q)

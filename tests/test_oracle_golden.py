@@ -1,0 +1,89 @@
+"""
+Pins the CPU oracle (oracle/trace_oracle.py) to the reference's own outputs.
+
+The fixtures were produced by tests/golden/make_golden.py, which ran the reference
+(torchlens.ray_tracing_lite) on CPU.  Forward must be BIT-EXACT in fp32; gradients
+w.r.t. the trace inputs must equal the reference autograd's.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from oracle import trace_oracle as orc
+
+RAY_CASES = ["G1_singlet_cfg1", "G2_cooke_16x16", "G4_doublet_32x32", "G4_tessar_32x32",
+             "G5_cooke_failures", "G6_cooke_aim1", "G10_cooke_noback", "G10_tessar_noback"]
+
+
+def _inputs(g, dtype=torch.float32, grad=False):
+    names = ("in_x", "in_y", "in_z", "in_cx", "in_cy", "in_c", "in_t", "in_mu")
+    ins = [torch.from_numpy(g[n]).to(dtype).requires_grad_(grad) for n in names]
+    return ins, torch.from_numpy(g["in_mask"]), bool(g.get("allow_backward_rays", True))
+
+
+@pytest.mark.parametrize("case", RAY_CASES)
+def test_forward_bit_exact(case):
+    g = load_golden(case)
+    ins, mask, allow = _inputs(g)
+    x, y, cx, cy, ok, back = orc.trace_skew(*ins, mask, False, allow)
+    for name, got in (("x", x), ("y", y), ("cx", cx), ("cy", cy)):
+        assert got.shape == g[name].shape
+        assert np.array_equal(got.numpy(), g[name]), f"{case}:{name} not bit-exact"
+    assert np.array_equal(ok.numpy(), g["ok"])
+    assert np.array_equal(back.numpy(), g["back"])
+    rms = orc.compute_rms2d(x, y, ok)
+    assert float(rms) == pytest.approx(float(g["rms_in"]), rel=0, abs=0)
+    # failed rays come out as exact zeros
+    dead = ~g["ok"] if allow else ~ok.numpy()
+    if allow:
+        assert not np.any(x.numpy()[dead]) and not np.any(y.numpy()[dead])
+
+
+@pytest.mark.parametrize("case", RAY_CASES)
+@pytest.mark.parametrize("prec", ["", "64"])
+def test_input_gradients_equal_reference(case, prec):
+    g = load_golden(case)
+    dtype = torch.float64 if prec else torch.float32
+    ins, mask, allow = _inputs(g, dtype, grad=True)
+    x, y, cx, cy, ok, back = orc.trace_skew(*ins, mask, False, allow)
+    rms = orc.compute_rms2d(x, y, ok)
+    gs = torch.autograd.grad(rms, ins, allow_unused=True)
+    assert float(rms.detach()) == float(g["rms_in" + prec])
+    for n, got in zip(("x", "y", "z", "cx", "cy", "c", "t", "mu"), gs):
+        want = g["gin_" + n + prec]
+        got = np.zeros_like(want) if got is None else got.numpy()
+        assert np.array_equal(got, want), f"{case}: d/d{n} differs (rel {rel_l2(got, want):.2e})"
+
+
+@pytest.mark.parametrize("case", ["G3_cooke_cfg2_d", "G3_cooke_cfg2_CdF"])
+def test_cfg2_scalars_present(case):
+    g = load_golden(case)
+    assert g["in_c"].shape[-1] == 7 and np.all(g["ok_frac"] == 1.0)
+    assert abs(float(g["rms_in"]) - float(g["rms_in64"])) < 1e-6
+
+
+def test_moment_closed_form_matches_rms():
+    """rms_from_moments (used by the sharded path) == compute_rms2d, failure-heavy case."""
+    g = load_golden("G5_cooke_failures")
+    ins, mask, allow = _inputs(g, torch.float64)
+    x, y, cx, cy, ok, back = orc.trace_skew(*ins, mask, False, allow)
+    want = orc.compute_rms2d(x, y, ok)
+    m = orc.spot_moments(y, ok)
+    got = orc.rms_from_moments(m, y.shape[2] * y.shape[3])
+    assert abs(float(got) - float(want)) < 1e-13
+    assert 0.5 < float(ok.double().mean()) < 0.9
+
+
+def test_aggregate_stacks_and_penalty():
+    g = load_golden("G7_harness_cooke")
+    ins, mask, allow = _inputs(g)
+    out = orc.trace_skew(*ins, mask, True, True)
+    stacks = out[6]
+    for key in ("z_RELU", "theta_norm", "theta_prime_norm"):
+        got = torch.stack(stacks[key], 0).numpy()
+        assert np.array_equal(got, g["stack_" + key], equal_nan=True), key
+    pen = orc.penalty_from_stacks(stacks, int(g["n_sequence"]))
+    assert float(pen) == float(np.float32(g["penalty"]))
+    rms = orc.compute_rms2d(out[0], out[1], out[4])
+    assert float(rms) == float(np.float32(g["rms"]))
