@@ -1,0 +1,138 @@
+/*
+ * tl_trace.h -- C ABI of the MI355X (gfx950) sequential ray-trace library, libtltrace.so
+ *
+ * The reference (OceanT-shirt/TorchOptics) has no FFI: its hot path is a chain of
+ * in-process Python calls.  Each entry point below states which reference function it
+ * stands in for (file:line under torchlens/); the Python host in torchoptics_amd/
+ * mirrors the reference signatures on top of these.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host";
+ *   - nothing is allocated here: the caller owns all buffers (stream-ordered borrow);
+ *   - functions are re-entrant and thread-safe (autograd calls backward from its own
+ *     thread; ray aiming re-enters the tracer inside a forward);
+ *   - return 0 on success, a negative TL_E* code otherwise; tl_last_error() gives the
+ *     message for the calling thread;
+ *   - the ray batch is [F fields][W wavelengths][P pupil points] with P contiguous
+ *     ("FWP" layout): one wavefront = 64 consecutive pupil points of one (f, w).
+ */
+#ifndef TL_TRACE_H
+#define TL_TRACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TL_ABI_VERSION 3
+#define TL_MAX_SURFACES 32       /* rows per lens the backward kernels are built for */
+#define TL_NMOM 8                /* spot moments per field, see tl_trace_fwd */
+#define TL_MAX_POLY 4            /* even aspheric terms a4,a6,a8,a10 */
+
+enum {
+    TL_OK = 0,
+    TL_EINVAL = -1,      /* bad argument (null pointer, bad size, S > TL_MAX_SURFACES ...) */
+    TL_ELAUNCH = -2,     /* HIP launch / runtime failure; message has hipGetErrorString */
+    TL_EWORKSPACE = -3   /* workspace too small, see tl_workspace_bytes */
+};
+
+enum { TL_MODE_STRICT = 0,   /* op-order-faithful fp32, no FMA contraction, IEEE sqrt and divide:
+                                forward bit-exact with the reference's eager fp32 ops        */
+       TL_MODE_FAST = 1 };   /* FMA contraction + hardware rcp/rsq; a few ulp from strict   */
+
+/*
+ * One trace problem.  Mirrors the argument list of
+ *   trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays)
+ *   (ray_tracing_lite.py:594) for one lens (B = 1).
+ */
+typedef struct tl_problem {
+    int32_t F, P, W, S;          /* fields, pupil points in this shard, wavelengths, surface rows */
+    int32_t device;              /* HIP device ordinal the pointers live on */
+    int32_t mode;                /* TL_MODE_* */
+    int32_t allow_backward;      /* allow_backward_rays (ray_tracing_lite.py:629) */
+    int32_t reserved0;
+    /* entrance-pupil ray coordinates; element strides (floats) over (f, p, w), 0 = broadcast.
+       Reference shapes [1|B, 1|F, P, 1|W] (ray_tracing_lite.py:112-113). */
+    const float *x_in, *y_in;
+    int64_t xs_f, xs_p, xs_w;
+    int64_t ys_f, ys_p, ys_w;
+    const float *z;              /* [1]   pupil position (ray_tracing_lite.py:91)            */
+    const float *cx, *cy;        /* [F] or [1] initial direction cosines (:116-118)          */
+    int32_t cx_stride, cy_stride;/* 1 or 0 (broadcast)                                       */
+    const float *c, *t;          /* [S]   curvature, thickness (:121-122)                    */
+    const float *mu;             /* [W,S] n_before/n_after per wavelength (:123)             */
+    const uint8_t *mask;         /* [S]   non-padding rows (:124)                            */
+    /* ---- aspheric extension (not in the reference; NULL = all-spherical) ---- */
+    const float *kappa;          /* [S]   conic constant, 0 = sphere                         */
+    const float *poly;           /* [S,TL_MAX_POLY] a4,a6,a8,a10                             */
+    const uint8_t *surf_kind;    /* [S]   0 = closed-form sphere, 1 = Newton asphere         */
+    const float *n_index;        /* [W,S+1] refractive indices for OPD, or NULL              */
+} tl_problem;
+
+int         tl_version(void);            /* == TL_ABI_VERSION */
+const char *tl_last_error(void);         /* host string, thread-local, never NULL */
+size_t      tl_problem_size(void);       /* sizeof(tl_problem): lets a foreign-language binding check its layout */
+
+/* Bytes of scratch (device) the calls below need for this problem. */
+size_t tl_workspace_bytes(const tl_problem *p);
+
+/*
+ * Forward trace: replaces the whole Python loop trace_skew (ray_tracing_lite.py:594-675 =
+ * find_marching_distance_spherical :525-545, update_ray_coordinates :514-522,
+ * reset_bad_rays :574-591, apply_snell_spherical :548-571, image-plane transfer :659-663).
+ *   x,y,cx,cy : [F,W,P] float  (any may be NULL = not wanted)
+ *   ok,back   : [F,W,P] uint8  (nullable)
+ *   opd       : [F,W,P] float  optical path length, needs p->n_index (nullable; extension)
+ *   moments   : [F,TL_NMOM] double (nullable), per field over (w,p):
+ *               0 sum y | 1 sum ok*y | 2 sum ok*y^2 | 3 sum ok | 4 sum x | 5 sum ok*x |
+ *               6 sum ok*x^2 | 7 sum back
+ *               -- the sufficient statistics of compute_rms2d (ray_tracing_lite.py:678-702),
+ *               reduced in a fixed order (bitwise reproducible).
+ */
+int tl_trace_fwd(const tl_problem *p,
+                 float *x, float *y, float *cx, float *cy, uint8_t *ok, uint8_t *back,
+                 float *opd, double *moments,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Backward trace: replaces PyTorch autograd's replay of the recorded graph of trace_skew
+ * (SURVEY 3.4).  Recomputes the forward per ray in registers, then sweeps the surfaces in
+ * reverse.
+ *   gx,gy,gcx,gcy : [F,W,P] upstream gradients of the per-ray outputs (each nullable)
+ *   g_moments     : [F,TL_NMOM] double upstream gradient of `moments` (nullable); the per-ray
+ *                   seed  gM0 + ok*(gM1 + 2*y*gM2)  (and the x analogue) is formed in-kernel
+ *   g_c,g_t [S], g_mu [W,S], g_z [1], g_cx,g_cy [F] : double, OVERWRITTEN (not accumulated)
+ *   g_kappa [S], g_poly [S,TL_MAX_POLY] : double, nullable (aspheric extension)
+ *   g_x_in,g_y_in : [F,W,P] float per-ray input gradients (nullable; used by ray aiming,
+ *                   ray_tracing_lite.py:169-181)
+ */
+int tl_trace_bwd(const tl_problem *p,
+                 const float *gx, const float *gy, const float *gcx, const float *gcy,
+                 const double *g_moments,
+                 double *g_c, double *g_t, double *g_mu, double *g_z, double *g_cx, double *g_cy,
+                 double *g_kappa, double *g_poly,
+                 float *g_x_in, float *g_y_in,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Spot moments of arbitrary per-ray tensors (same TL_NMOM layout): the reduction inside
+ * compute_rms2d(x, y, ray_ok) (ray_tracing_lite.py:678-702) when its inputs did not come
+ * from tl_trace_fwd.  Element strides over (f, p, w); x may be NULL.
+ */
+int tl_spot_moments(int32_t device, int32_t F, int32_t P, int32_t W,
+                    const float *x, const float *y, const uint8_t *ok,
+                    int64_t s_f, int64_t s_p, int64_t s_w,
+                    double *moments, void *workspace, size_t workspace_bytes, void *stream);
+
+/* d(loss)/dy, d(loss)/dx per ray from d(loss)/d(moments); outputs [F,P,W]-strided like y. */
+int tl_spot_seed(int32_t device, int32_t F, int32_t P, int32_t W,
+                 const float *x, const float *y, const uint8_t *ok,
+                 int64_t s_f, int64_t s_p, int64_t s_w,
+                 const double *g_moments, float *gx, float *gy, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TL_TRACE_H */

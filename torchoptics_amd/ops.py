@@ -1,0 +1,209 @@
+"""
+autograd.Function wrappers around the C ABI (include/tl_trace.h).
+
+`TraceFunction` stands where PyTorch autograd's recorded graph of the reference's
+`trace_skew` stood (ray_tracing_lite.py:594-675): forward = one fused HIP kernel,
+backward = one recompute-and-reverse HIP kernel.  `SpotMomentsFunction` is the reduction of
+`compute_rms2d` (ray_tracing_lite.py:678-702) for tensors that did not come from the trace.
+
+Per-ray buffers are allocated [F, W, P] (pupil index contiguous) and handed
+out as [1, F, P, W] permuted views, which is the reference's logical shape.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+from ._lib import TL_NMOM, tl_problem
+
+_MODES = {"strict": _lib.MODE_STRICT, "fast": _lib.MODE_FAST}
+_default_mode = os.environ.get("TORCHOPTICS_AMD_MODE", "strict")
+
+
+def set_default_mode(mode: str) -> None:
+    """'strict' (bit-faithful fp32 op order) or 'fast' (FMA contraction, hardware rcp/sqrt)."""
+    global _default_mode
+    if mode not in _MODES:
+        raise ValueError(f"mode must be one of {tuple(_MODES)}")
+    _default_mode = mode
+
+
+def get_default_mode() -> str:
+    return _default_mode
+
+
+def _require_device(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"torchoptics_amd: `{name}` lives on {t.device}; the ray tracer runs only as HIP kernels on an "
+            "AMD GPU (there is no CPU fallback).  Move the lens and rays to device='cuda'.")
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Per-(device, stream) scratch for the block partials; grows monotonically."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode):
+    F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
+    p = tl_problem()
+    p.F, p.P, p.W, p.S = F, P, W, c.numel()
+    p.device = x_e.device.index
+    p.mode = _MODES[mode]
+    p.allow_backward = 1 if allow_back else 0
+    p.x_in, p.y_in = x_e.data_ptr(), y_e.data_ptr()
+    p.xs_f, p.xs_p, p.xs_w = x_e.stride(1), x_e.stride(2), x_e.stride(3)
+    p.ys_f, p.ys_p, p.ys_w = y_e.stride(1), y_e.stride(2), y_e.stride(3)
+    p.z, p.cx, p.cy = z.data_ptr(), cx.data_ptr(), cy.data_ptr()
+    p.cx_stride = 0 if cx.numel() == 1 else 1
+    p.cy_stride = 0 if cy.numel() == 1 else 1
+    p.c, p.t, p.mu, p.mask = c.data_ptr(), t.data_ptr(), mu.data_ptr(), mask_u8.data_ptr()
+    p.kappa = p.poly = p.surf_kind = p.n_index = None
+    return p
+
+
+def _fwp(t):
+    """[1,F,P,W] logical tensor -> memory laid out [F,W,P] contiguous (no copy if it already is)."""
+    return t.permute(0, 1, 3, 2).contiguous()
+
+
+class TraceFunction(torch.autograd.Function):
+    """(x, y, cx, cy, ok, back, moments) = trace(x_in, y_in, z, cx, cy, c, t, mu)."""
+
+    @staticmethod
+    def forward(ctx, x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, want_rays):
+        for name, ten in (("x", x_e), ("y", y_e), ("z", z), ("cx", cx), ("cy", cy), ("c", c), ("t", t),
+                          ("mu", mu), ("mask", mask_u8)):
+            _require_device(ten, name)
+        dev = x_e.device
+        F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
+        S = c.numel()
+        if S > _lib.TL_MAX_SURFACES:
+            raise RuntimeError(f"lens has {S} rows; this build supports at most {_lib.TL_MAX_SURFACES}")
+        lib = _lib.lib()
+        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode)
+        nbytes = lib.tl_workspace_bytes(C.byref(prob))
+        ws = _workspace(nbytes, dev)
+        if want_rays:
+            fp = [torch.empty((1, F, W, P), dtype=torch.float32, device=dev) for _ in range(4)]
+            bp = [torch.empty((1, F, W, P), dtype=torch.uint8, device=dev) for _ in range(2)]
+        else:
+            fp, bp = [None] * 4, [None] * 2
+        moments = torch.empty((F, TL_NMOM), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.tl_trace_fwd(C.byref(prob), *[_lib.ptr(b) for b in fp], *[_lib.ptr(b) for b in bp],
+                                  None, _lib.ptr(moments), _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "tl_trace_fwd")
+        ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8)
+        ctx.allow_back, ctx.mode = allow_back, mode
+        ctx.set_materialize_grads(False)
+        if want_rays:
+            outs = [b.permute(0, 1, 3, 2) for b in fp]
+            flags = [b.view(torch.bool).permute(0, 1, 3, 2) for b in bp]
+        else:
+            outs = [torch.empty(0, device=dev) for _ in range(4)]
+            flags = [torch.empty(0, dtype=torch.bool, device=dev) for _ in range(2)]
+        ctx.mark_non_differentiable(*flags)
+        return (*outs, *flags, moments)
+
+    @staticmethod
+    def backward(ctx, gx, gy, gcx, gcy, _gok, _gback, gmom):
+        x_e, y_e, z, cx, cy, c, t, mu, mask_u8 = ctx.saved_tensors
+        dev = x_e.device
+        F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
+        S = c.numel()
+        if gx is None and gy is None and gcx is None and gcy is None and gmom is None:
+            return (None,) * 12
+        lib = _lib.lib()
+        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, ctx.allow_back, ctx.mode)
+        ws = _workspace(lib.tl_workspace_bytes(C.byref(prob)), dev)
+
+        def dense(g):
+            if g is None or g.numel() == 0:
+                return None
+            return _fwp(g.to(torch.float32))
+        gxd, gyd, gcxd, gcyd = dense(gx), dense(gy), dense(gcx), dense(gcy)
+        gmd = None if gmom is None else gmom.to(torch.float64).contiguous()
+        need_xin, need_yin = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gxin = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if need_xin else None
+        gyin = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if need_yin else None
+        gpar = torch.empty(2 * S + W * S + 1 + 2 * F, dtype=torch.float64, device=dev)
+        g_c, g_t, g_mu, g_z, g_cx, g_cy = torch.split(gpar, [S, S, W * S, 1, F, F])
+        with torch.cuda.device(dev):
+            rc = lib.tl_trace_bwd(C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd),
+                                  _lib.ptr(gmd), _lib.ptr(g_c), _lib.ptr(g_t), _lib.ptr(g_mu), _lib.ptr(g_z),
+                                  _lib.ptr(g_cx), _lib.ptr(g_cy), None, None, _lib.ptr(gxin), _lib.ptr(gyin),
+                                  _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "tl_trace_bwd")
+        f32 = gpar.to(torch.float32)
+        g_c, g_t, g_mu, g_z, g_cx, g_cy = torch.split(f32, [S, S, W * S, 1, F, F])
+        if cx.numel() == 1:
+            g_cx = g_cx.sum(dim=0, keepdim=True)
+        if cy.numel() == 1:
+            g_cy = g_cy.sum(dim=0, keepdim=True)
+        return (gxin.permute(0, 1, 3, 2) if need_xin else None,
+                gyin.permute(0, 1, 3, 2) if need_yin else None,
+                g_z.reshape(z.shape), g_cx.reshape(cx.shape), g_cy.reshape(cy.shape),
+                g_c.reshape(c.shape), g_t.reshape(t.shape), g_mu.reshape(mu.shape),
+                None, None, None, None)
+
+
+class SpotMomentsFunction(torch.autograd.Function):
+    """moments[F, 8] of arbitrary per-ray tensors x, y, ok shaped [1, F, P, W]."""
+
+    @staticmethod
+    def forward(ctx, x, y, ok):
+        _require_device(y, "y")
+        dev = y.device
+        _, F, P, W = y.shape
+        if y.dtype != torch.float32 or any(s == 0 for s in y.stride()[1:]):
+            y = y.to(torch.float32).contiguous()
+        xs = None
+        if x is not None:
+            xs = x.to(torch.float32)
+            if xs.stride() != y.stride():
+                xs = torch.empty_strided(y.shape, y.stride(), dtype=torch.float32, device=dev).copy_(xs)
+        oks = ok.view(torch.uint8) if ok.dtype == torch.bool else ok.to(torch.uint8)
+        if oks.stride() != y.stride():
+            oks = torch.empty_strided(y.shape, y.stride(), dtype=torch.uint8, device=dev).copy_(oks)
+        lib = _lib.lib()
+        moments = torch.empty((F, TL_NMOM), dtype=torch.float64, device=dev)
+        ws = _workspace(F * W * ((P + 255) // 256) * TL_NMOM * 8 + 256, dev)
+        with torch.cuda.device(dev):
+            rc = lib.tl_spot_moments(dev.index, F, P, W, _lib.ptr(xs), _lib.ptr(y), _lib.ptr(oks),
+                                     y.stride(1), y.stride(2), y.stride(3), _lib.ptr(moments),
+                                     _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "tl_spot_moments")
+        ctx.save_for_backward(xs if xs is not None else y, y, oks)
+        ctx.has_x = xs is not None
+        return moments
+
+    @staticmethod
+    def backward(ctx, gmom):
+        xs, y, oks = ctx.saved_tensors
+        dev = y.device
+        _, F, P, W = y.shape
+        lib = _lib.lib()
+        gm = gmom.to(torch.float64).contiguous()
+        gy = torch.empty_strided(y.shape, y.stride(), dtype=torch.float32, device=dev)
+        need_x = ctx.has_x and ctx.needs_input_grad[0]
+        gx = torch.empty_strided(y.shape, y.stride(), dtype=torch.float32, device=dev) if need_x else None
+        with torch.cuda.device(dev):
+            rc = lib.tl_spot_seed(dev.index, F, P, W, _lib.ptr(xs) if ctx.has_x else None, _lib.ptr(y),
+                                  _lib.ptr(oks), y.stride(1), y.stride(2), y.stride(3), _lib.ptr(gm),
+                                  _lib.ptr(gx), _lib.ptr(gy), _stream_ptr(dev))
+        _lib.check(rc, "tl_spot_seed")
+        return gx, gy, None

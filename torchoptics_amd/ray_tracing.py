@@ -1,0 +1,266 @@
+"""
+Sequential ray tracer: drop-in for the reference's `torchlens/ray_tracing_lite.py`.
+
+Public names and signatures follow the reference (`RayTracer` ray_tracing_lite.py:26-208,
+`trace_skew` :594-675, `compute_rms2d` :678-702, samplers :353-422, `scale_to_epd` :497-507),
+but the per-surface Python loop of ~86 eager tensor ops is gone: `trace_skew` is ONE fused HIP
+kernel (and one hand-written backward kernel) reached through the C ABI in
+include/tl_trace.h.  There is no CPU implementation in this package: CPU tensors raise.
+
+Tensor dims, as in the reference: [lens (=1), field, pupil, wavelength(, surface)].
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import TL_NMOM
+from .paraxial import (compute_last_curvature, compute_magnification, compute_pupil_position,  # noqa: F401
+                       compute_pupil_radius, get_first_order, interface_propagation_abcd, reduce_abcd)
+
+_LINES = {'C': 656.3, 'd': 587.6, 'F': 486.1}
+_WORKING_MODES = ('skew_random', 'tee', 'circular')
+_UNPORTED_MODES = ('skew_uniform_half_equidistant', 'skew_uniform_half_jittered', 'skew_inner_square_half',
+                   'skew_outer_edge_uniform', 'meridional_uniform', 'sagittal_uniform', 'chief')
+
+
+# ---------------------------------------------------------------------------- pupil samplers
+def tee(tensor=None, device="cuda"):
+    """Bottom and top meridional rays and the +x sagittal ray, shape [1,1,3,1]."""
+    y = torch.tensor([-1., 1., 0.], device=device).reshape(1, 1, 3, 1)
+    x = torch.tensor([0., 0., 1.], device=device).reshape(1, 1, 3, 1)
+    return x, y
+
+
+def circle(tensor, n_r, n_theta, default_device="cuda"):
+    """Polar grid: radii linspace(0,1,n_r) and angles linspace(0,2pi,n_theta), both without the
+    end point -- so n_theta coincident rays at r=0 and none at r=1 (reference quirk B7, kept)."""
+    r = torch.from_numpy(np.linspace(0, 1.0, n_r, endpoint=False, dtype=np.float32)).to(default_device)
+    th = torch.from_numpy(np.linspace(0, 2 * np.pi, n_theta, endpoint=False, dtype=np.float32)).to(default_device)
+    x = r[None, :, None] * torch.cos(th)[None, None, :]
+    y = r[None, :, None] * torch.sin(th)[None, None, :]
+    return x.reshape(-1, 1, n_r * n_theta, 1), y.reshape(-1, 1, n_r * n_theta, 1)
+
+
+def circle_index_range(n_r, n_theta, start, stop, default_device="cuda"):
+    """Points [start, stop) of `circle`'s grid generated from their indices (pupil sharding:
+    every rank builds its own contiguous slice; bit-identical to slicing the full grid)."""
+    r_all = torch.from_numpy(np.linspace(0, 1.0, n_r, endpoint=False, dtype=np.float32)).to(default_device)
+    th_all = torch.from_numpy(np.linspace(0, 2 * np.pi, n_theta, endpoint=False, dtype=np.float32)).to(default_device)
+    idx = torch.arange(start, stop, device=default_device)
+    r, th = r_all[idx // n_theta], th_all[idx % n_theta]
+    return (r * torch.cos(th)).reshape(1, 1, -1, 1), (r * torch.sin(th)).reshape(1, 1, -1, 1)
+
+
+def circle_pseudo_random(tensor, n_r, n_theta):
+    """Stratified jitter over the unit disc; draws from the global CPU torch RNG like the
+    reference (two torch.rand calls of shape [numel, n_r, n_theta])."""
+    n_el = int(np.prod(tensor.shape))
+    d_r2 = torch.rand((n_el, n_r, n_theta)) / n_r
+    d_th = torch.rand((n_el, n_r, n_theta)) / n_theta
+    r2_0 = torch.tensor(np.linspace(0, 1, n_r, endpoint=False, dtype=np.float32))[None, :, None]
+    th_0 = torch.tensor(np.linspace(0, 1, n_theta, endpoint=False, dtype=np.float32))[None, None, :]
+    r = torch.sqrt(d_r2 + r2_0)
+    th = (d_th + th_0) * 2 * np.pi
+    n = n_r * n_theta
+    return (r * torch.cos(th)).view(-1, 1, n, 1), (r * torch.sin(th)).view(-1, 1, n, 1)
+
+
+def scale_to_epd(y, epd):
+    """Relative pupil coordinate -> height at the pupil plane: y * epd / 2."""
+    return y * epd.reshape(-1, *([1] * (y.dim() - 1))) / 2
+
+
+# ---------------------------------------------------------------------------- the hot path
+def _as_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name} must be a tensor")
+    return t if t.dtype == torch.float32 else t.to(torch.float32)
+
+
+def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_rays=True, mode=None,
+               want_rays=True):
+    """Trace rays from the entrance pupil to the image plane through S spherical rows.
+
+    Same contract as the reference (ray_tracing_lite.py:594-675): inputs broadcast to
+    [1, F, P, W]; returns (x, y, cx, cy, ray_ok, ray_backward).  Differentiable w.r.t.
+    x, y, z, cx, cy, c, t, mu through a hand-written backward kernel.
+
+    Extras (not in the reference): `mode` 'strict'|'fast' (default ops.get_default_mode());
+    the returned `y` carries the fused spot moments so `compute_rms2d(x, y, ray_ok)` costs no
+    second pass over the rays.
+    """
+    if aggregate:
+        raise NotImplementedError("aggregate=True (per-surface penalty stacks) is not built yet; "
+                                  "see DESIGN.md 'next rows'")
+    x, y, z, cx, cy = (_as_f32(a, n) for a, n in ((x, 'x'), (y, 'y'), (z, 'z'), (cx, 'cx'), (cy, 'cy')))
+    c, t, mu = _as_f32(c, 'c'), _as_f32(t, 't'), _as_f32(mu, 'mu')
+    for a, n in ((x, 'x'), (y, 'y'), (cx, 'cx'), (cy, 'cy'), (z, 'z')):
+        if a.dim() != 4 or a.shape[0] != 1:
+            raise ValueError(f"{n} must be 4-D with a single lens in dim 0 (B=1), got {tuple(a.shape)}")
+    if c.dim() != 5 or c.shape[0] != 1 or mu.dim() != 5:
+        raise ValueError("c, t, mu must be 5-D [1,1,1,1|W,S]")
+    S = c.shape[-1]
+    F = max(x.shape[1], y.shape[1], cx.shape[1], cy.shape[1])
+    P = max(x.shape[2], y.shape[2])
+    W = max(x.shape[3], y.shape[3], mu.shape[3])
+    if z.numel() != 1:
+        raise ValueError("z must hold one pupil position (B=1)")
+    x_e, y_e = x.expand(1, F, P, W), y.expand(1, F, P, W)
+    cxv = cx.reshape(-1).contiguous()
+    cyv = cy.reshape(-1).contiguous()
+    if cxv.numel() not in (1, F) or cyv.numel() not in (1, F):
+        raise ValueError("cx, cy must be per-field [1,F,1,1] or a single value")
+    mu2 = mu.reshape(mu.shape[3], S).expand(W, S).contiguous()
+    mask_u8 = mask.reshape(-1).to(torch.uint8).contiguous()
+    out = ops.TraceFunction.apply(x_e, y_e, z.reshape(1).contiguous(), cxv, cyv, c.reshape(S).contiguous(),
+                                  t.reshape(S).contiguous(), mu2, mask_u8, bool(allow_backward_rays),
+                                  mode or ops.get_default_mode(), want_rays)
+    xo, yo, cxo, cyo, ok, back, moments = out
+    if want_rays:
+        # remember which moments belong to these rays (checked by identity + version in compute_rms2d)
+        yo._tl_spot = (moments, ok, yo._version, P * W)
+        return xo, yo, cxo, cyo, ok, back
+    return moments
+
+
+def rms_from_moments(moments: torch.Tensor, n_per_field: int) -> torch.Tensor:
+    """compute_rms2d written on the per-field moments (fp64): with m = M0/n,
+    rms = mean_f sqrt((M2 - 2 m M1 + m^2 M3) / n).  Failed rays count as y = 0 in the
+    centroid and in the denominator, exactly like the reference (quirk B8)."""
+    m = moments[:, 0] / n_per_field
+    var = (moments[:, 2] - 2 * m * moments[:, 1] + m * m * moments[:, 3]) / n_per_field
+    return torch.sqrt(var).mean()
+
+
+def compute_rms2d(x, y, ray_ok, group=None, n_per_field: Optional[int] = None):
+    """Mean over fields of the y-RMS spot radius of lens 0 (ray_tracing_lite.py:678-702).
+
+    `group`: a torch.distributed process group over which the pupil dimension is sharded; the
+    per-field moments are summed across it (one tiny all-reduce) before the closed form.
+    `n_per_field`: P*W of the WHOLE (unsharded) pupil; defaults to this shard's P*W times the
+    group size.
+    """
+    tag = getattr(y, "_tl_spot", None)
+    if tag is not None and tag[1] is ray_ok and tag[2] == y._version:
+        moments, n_local = tag[0], tag[3]
+    else:
+        moments = ops.SpotMomentsFunction.apply(x, y, ray_ok)
+        n_local = y.shape[2] * y.shape[3]
+    if group is not None:
+        from . import dist as tl_dist
+        moments = tl_dist.all_reduce_sum(moments, group)
+        if n_per_field is None:
+            n_per_field = n_local * torch.distributed.get_world_size(group)
+    rms = rms_from_moments(moments, n_per_field or n_local)
+    return rms.to(y.dtype)
+
+
+# ---------------------------------------------------------------------------- RayTracer
+class RayTracer:
+    """Builds the ray fan for a `Specs`/`Lens` pair and traces it (ray_tracing_lite.py:26-208)."""
+
+    def __init__(self, mode='skew_random', n_rays=(8, 8), rel_fields=(0., 0.707, 1.), vig_fn=None,
+                 double_precision=False, wavelengths=(656.3, 587.6, 486.1), n_ray_aiming_iter=0,
+                 ray_aiming_mode='real', allow_backward_rays=True, default_device='cuda', arith=None):
+        self.mode = mode
+        self.default_device = default_device
+        if mode in ('skew_random', 'circular'):
+            assert len(n_rays) == 2
+        if mode == 'skew_random':
+            self.pupil_span = lambda tensor: circle_pseudo_random(tensor, *n_rays)
+        elif mode == 'circular':
+            self.pupil_span = lambda tensor: circle(tensor, *n_rays, self.default_device)
+        elif mode == 'tee':
+            self.pupil_span = lambda tensor: tee(tensor, self.default_device)
+        elif mode in _UNPORTED_MODES:
+            raise NotImplementedError(f"pupil sampling mode '{mode}' has no working definition in the "
+                                      f"reference PyTorch port (it raises NameError there); use one of {_WORKING_MODES}")
+        else:
+            raise ValueError(f"Ray tracing mode must be one of {_WORKING_MODES + _UNPORTED_MODES}")
+        if vig_fn is not None:
+            raise NotImplementedError("vignetting functions are not supported (broken in the reference port too)")
+        if double_precision:
+            raise NotImplementedError("the HIP kernels compute in fp32; double_precision is not available")
+        self.n_rays = n_rays
+        self.rel_fields = rel_fields
+        self.vig_fn = vig_fn
+        self.n_ray_aiming_iter = n_ray_aiming_iter
+        self.ray_aiming_mode = ray_aiming_mode
+        self.allow_backward_rays = allow_backward_rays
+        self.wavelengths = [_LINES.get(w, w) for w in wavelengths]
+        self.double_precision = double_precision
+        self.arith = arith      # None -> ops.get_default_mode()
+
+    # -- host-side assembly of the kernel arguments (ray_tracing_lite.py:86-124) -------------
+    def assemble(self, specs, lens, xy=None, up_to_stop=False, use_vig=True):
+        """Everything `trace_skew` needs, as a dict: x, y, z, cx, cy, c, t, mu, mask."""
+        dev = self.default_device
+        n = lens.get_refractive_indices(self.wavelengths)                 # [1, S, W]
+        n = torch.cat((torch.ones_like(n[:, :1, :]), n), dim=1).transpose(1, 2)
+        n = n.reshape(n.shape[0], 1, 1, n.shape[1], -1)                   # [1,1,1,W,S+1]
+        z = compute_pupil_position(lens).reshape(-1, 1, 1, 1)
+        xp_rel, yp_rel = self.pupil_span(z) if xy is None else xy
+        if self.n_ray_aiming_iter > 0 and not up_to_stop:
+            aim = self.ray_aiming(specs, lens.detach(), use_vig)
+            xp_rel, yp_rel = (torch.clamp(v, -2, 2).to(dev).detach() for v in aim(xp_rel, yp_rel))
+        fields = torch.tensor(self.rel_fields, dtype=torch.float32).to(dev)
+        cy = torch.sin((specs.hfov[:, None] * fields[None, :])[..., None, None])
+        cx = torch.zeros(1, device=dev).reshape(1, 1, 1, 1)
+        return dict(
+            x=scale_to_epd(xp_rel.to(dev), specs.epd), y=scale_to_epd(yp_rel.to(dev), specs.epd), z=z, cx=cx, cy=cy,
+            c=lens.c.reshape(lens.c.shape[0], 1, 1, 1, -1), t=lens.t.reshape(lens.t.shape[0], 1, 1, 1, -1),
+            mu=n[..., :-1] / n[..., 1:],
+            mask=lens.structure.mask_torch.reshape(lens.c.shape[0], 1, 1, 1, -1))
+
+    def trace_rays(self, specs, lens, use_vig=True, aggregate=False, xy=None, up_to_stop=False):
+        a = self.assemble(specs, lens, xy=xy, up_to_stop=up_to_stop, use_vig=use_vig)
+        return trace_skew(a['x'], a['y'], a['z'], a['cx'], a['cy'], a['c'], a['t'], a['mu'], a['mask'],
+                          aggregate, self.allow_backward_rays, mode=self.arith)
+
+    # -- ray aiming (ray_tracing_lite.py:129-208) ---------------------------------------------
+    def ray_aiming(self, specs, lens, use_vig):
+        """One Newton step per iteration on the pupil coordinates of three 'tee' rays so that
+        they land on the stop where an ideal pupil would put them; returns the affine pupil
+        remap.  The Jacobian diagonal comes from the backward kernel's per-ray input grads."""
+        if (lens.structure.stop_idx == 0).all():
+            return lambda xp_rel, yp_rel: (xp_rel, yp_rel)
+        if self.n_ray_aiming_iter > 1:
+            raise NotImplementedError("n_ray_aiming_iter >= 2 fails in the reference as well (Appendix B4)")
+        specs2stop, lens2stop = specs.up_to_stop(), lens.up_to_stop()
+        if self.ray_aiming_mode == 'paraxial':
+            rs = (compute_magnification(lens2stop) * specs2stop.epd / 2).reshape(-1, 1, 1, 1)
+        elif self.ray_aiming_mode == 'real':
+            rs = compute_pupil_radius(specs2stop, lens2stop, default_device=self.default_device).reshape(-1, 1, 1, 1)
+        else:
+            raise ValueError("ray_aiming_mode must be 'real' or 'paraxial'")
+
+        xt0, yt0 = tee(None, self.default_device)
+        shape = (len(lens), len(self.rel_fields), xt0.shape[2], len(self.wavelengths))
+        xt_ref, yt_ref = xt0.expand(shape).clone(), yt0.expand(shape).clone()
+        with torch.enable_grad():
+            xt = xt_ref.clone().requires_grad_(True)
+            yt = yt_ref.clone().requires_grad_(True)
+            xs, ys, *_ = self.trace_rays(specs2stop, lens2stop, up_to_stop=True, use_vig=False, xy=(xt, yt))
+            xs_rel, ys_rel = xs / rs, ys / rs
+            # the reference back-propagates ones through xs_rel and then ys_rel into the same .grad
+            jx, jy = torch.autograd.grad(xs_rel.sum() + ys_rel.sum(), (xt, yt))
+        xs_rel, ys_rel, xt, yt = xs_rel.detach(), ys_rel.detach(), xt.detach(), yt.detach()
+        dx = -(xs_rel - xt_ref) / jx
+        dy = -(ys_rel - yt_ref) / jy
+        dx = torch.where(torch.isfinite(dx), dx, torch.zeros_like(dx))
+        dy = torch.where(torch.isfinite(dy), dy, torch.zeros_like(dy))
+        dx_s = dx[..., -1:, :]
+        dy_l, dy_u = dy[..., 0:1, :], dy[..., 1:2, :]
+        x_s = xt[..., -1:, :]
+        y_l, y_u = yt[..., 0:1, :], yt[..., 1:2, :]
+        y_scale = (y_u + dy_u - (y_l + dy_l)) / (y_u - y_l)
+        y_offset = (y_l * dy_u - y_u * dy_l) / (y_l - y_u)
+
+        def remap(xp_rel, yp_rel):
+            return xp_rel * (x_s + dx_s) / x_s, yp_rel * y_scale + y_offset
+        return remap
