@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""
+bench.py -- rays/s of the sequential ray-trace hot path, forward + backward, on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5] [--mode strict|fast]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+A "step" is one pass of the hot path over one resident batch of rays: trace_skew (fused forward
+kernel, per-ray outputs materialised as the reference API returns them, spot moments fused) ->
+compute_rms2d (closed form on the moments; one tiny all-reduce when N > 1) -> backward (recompute
++ adjoint kernel) -> gradients of the loss w.r.t. the trace parameters (c, t, mu, z, cy) [-> one
+tiny all-reduce when N > 1].  The pupil coordinates are resident in HBM before the timed region.
+
+Workloads:
+  cfg3 (default): synthesized double Gauss, 11 rows (10 refracting surfaces + stop), F=1 field
+        (0.707), W=1 ('d'), circular pupil grid 4096 x 4096 = 2^24 rays PER GPU (weak scaling; at
+        N=8 this is cfg4's 2^27 rays).  This is the config BASELINE.json's metric ("M rays/s
+        through 10-surface lens; fwd+bwd") is quoted on.
+  cfg2: Cooke triplet (7 rows), 1024 x 1024 pupil, 3 fields, W=1.
+  cfg5: 20-row synthetic zoom, 5 fields x 3 wavelengths, 1024 x 1024 pupil.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector (packed FMA)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5"])
+    ap.add_argument("--mode", default=os.environ.get("TORCHOPTICS_AMD_MODE", "strict"), choices=["strict", "fast"])
+    ap.add_argument("--log2-pupil", type=int, default=None, help="override log2 of pupil points per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log2-rays", type=int, default=21, help="log2 of the CPU-baseline sample (rays)")
+    return ap.parse_args()
+
+
+def workload(name, device, world, rank, log2_pupil):
+    """Returns dict(lens args as leaves, pupil slice, meta)."""
+    import torchoptics_amd as ta
+    from torchoptics_amd import prescriptions as P, ray_tracing as rt
+    if name == "cfg3":
+        lens, specs, leaves = P.double_gauss(device)
+        fields, wl, lp = (0.707,), ("d",), 24
+    elif name == "cfg2":
+        import yaml_free_lenses as L
+        lens, specs, leaves = L.build("cooke", device)
+        fields, wl, lp = (0., 0.707, 1.), ("d",), 20
+    else:
+        lens, specs, leaves = P.zoom20(device)
+        fields, wl, lp = tuple(np.linspace(0, 1, 5)), ("C", "d", "F"), 20
+    lp = log2_pupil if log2_pupil is not None else lp
+    p_local = 1 << lp
+    n_r = 1 << (lp // 2)
+    n_theta_total = (p_local // n_r) * world            # weak scaling: the grid grows with N
+    tr = ta.RayTracer(mode="circular", n_rays=(n_r, n_theta_total), rel_fields=fields, wavelengths=wl,
+                      default_device=device)
+    xy = rt.circle_index_range(n_r, n_theta_total, rank * p_local, (rank + 1) * p_local, device)
+    with torch.no_grad():
+        a = tr.assemble(specs, lens, xy=xy)
+    args = {k: v.detach().clone() for k, v in a.items()}
+    for k in ("z", "cy", "c", "t", "mu"):
+        args[k].requires_grad_(True)
+    meta = dict(F=len(fields), W=len(wl), S=lens.c.shape[1], P_local=p_local, P_total=p_local * world,
+                lens=name, fields=list(map(float, fields)), wavelengths=list(wl))
+    return args, meta, (tr, specs, lens, leaves, xy)
+
+
+def flops_per_ray(S):
+    """fp32 arithmetic operations per ray as written in csrc/tl_kernels.inc (mul, add/sub, sqrt, div,
+    rcp each count 1; compares, selects, negations not counted; counted by hand):
+    step_fwd 54 per surface (+5 image plane); step_bwd 49 recompute + 99 adjoint per surface; the
+    backward kernel runs step_fwd once more to reach the image plane (+30 seeds/entrance)."""
+    fwd = 54 * S + 5
+    bwd = fwd + (49 + 99) * S + 30
+    return fwd, bwd
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs an AMD GPU"
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+        group = dist.group.WORLD
+
+    import torchoptics_amd as ta
+    from torchoptics_amd import _lib, ops, dist as tl_dist
+    _lib.lib()      # fail loudly when the HIP library is missing
+    ops.set_default_mode(a.mode)
+
+    args, meta, extra = workload(a.workload, device, world, rank, a.log2_pupil)
+    leaves = [args[k] for k in ("z", "cy", "c", "t", "mu")]
+    n_per_field_total = meta["P_total"] * meta["W"]
+
+    def step():
+        for p in leaves:
+            p.grad = None
+        x, y, cx, cy, ok, back = ta.trace_skew(args["x"], args["y"], args["z"], args["cx"], args["cy"], args["c"],
+                                               args["t"], args["mu"], args["mask"])
+        rms = ta.compute_rms2d(x, y, ok, group=group, n_per_field=n_per_field_total)
+        rms.backward()
+        if group is not None:
+            tl_dist.all_reduce_grads(leaves, group)
+        return rms
+
+    def sync():
+        if group is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        rms = step()
+    sync()
+    ops.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rms = step()
+    sync()
+    dt = time.perf_counter() - t0
+    kern_ms = ops.timing_ms()
+    ops.enable_timing(False)
+    if group is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = tmax.item()
+
+    rays_local = meta["F"] * meta["W"] * meta["P_local"]
+    rays_total = rays_local * world
+    ms_per_step = dt / a.steps * 1e3
+    value = rays_total * a.steps / dt / 1e6
+
+    # ---- roofline of the dominant kernel (trace_bwd_kernel), per launch, from live event timing
+    fw = meta["F"] * meta["W"]
+    b_fwd, b_bwd = 18.0 + 8.0 / fw, 8.0 / fw      # algorithmic bytes per ray (DESIGN.md "bytes per unit")
+    f_fwd, f_bwd = flops_per_ray(meta["S"])
+    kernels = {}
+    for key, bpr, fpr in (("fwd", b_fwd, f_fwd), ("bwd", b_bwd, f_bwd)):
+        ms = kern_ms.get(key)
+        if ms:
+            kernels[key] = dict(ms=ms, rays_per_s=rays_local / ms * 1e3, hbm_GBs=rays_local * bpr / ms / 1e6,
+                                valu_TFLOPs=rays_local * fpr / ms / 1e9, bytes_per_ray=bpr, flops_per_ray=fpr)
+    dom = kernels.get("bwd")
+    roofline = None
+    if dom:
+        roofline = dict(kernel="trace_bwd_kernel", bound="hbm", achieved=dom["hbm_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=dom["hbm_GBs"] / HBM_PEAK_GBS, traffic=None, launch_ms=dom["ms"],
+                        note="per-ray FMA kernel: the binding limit is the FP32 vector ALU, see roofline_valu")
+    roofline_valu = None
+    if dom:
+        roofline_valu = dict(kernel="trace_bwd_kernel", bound="valu_fp32", achieved=dom["valu_TFLOPs"],
+                             peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=dom["valu_TFLOPs"] / VALU_PEAK_TFLOPS)
+    # whole-step algorithmic HBM rate (fwd + bwd bytes at the API boundary, SURVEY 8d headline)
+    step_bytes = rays_total * (b_fwd + b_bwd)
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu_baseline = cpu_leg(args, meta, a.cpu_log2_rays)
+
+    if rank == 0:
+        out = {
+            "metric": "M rays/s through 10-surface lens; fwd+bwd; grad rel-err vs PyTorch autograd",
+            "value": value, "unit": "M rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {meta['lens']} S={meta['S']} rows, F={meta['F']} W={meta['W']} "
+                                   f"P={meta['P_local']} pupil points per GPU ({rays_local} rays/GPU, {rays_total} total), "
+                                   f"circular grid, loss=compute_rms2d, fwd+bwd",
+                       "arith_mode": a.mode, "parallelism": f"pupil-sharded dp{world}", "rms": float(rms.item())},
+            "roofline": roofline, "roofline_valu": roofline_valu, "kernels": kernels,
+            "step_hbm_GBs": step_bytes / (dt / a.steps) / 1e9,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if group is not None:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_leg(args, meta, log2_rays):
+    """The oracle (CPU restatement of the reference, eager PyTorch fp32 + autograd) timed on this
+    box's host cores on a bounded sample of the same workload: the first 2^log2_rays/(F*W) pupil
+    points.  kind='port': the reference itself cannot travel to the GPU box."""
+    from oracle import trace_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    fw = meta["F"] * meta["W"]
+    p = max(1, min(meta["P_local"], (1 << log2_rays) // fw))
+    cpu = {k: v.detach().cpu() for k, v in args.items()}
+    cpu["x"], cpu["y"] = cpu["x"][:, :, :p].contiguous(), cpu["y"][:, :, :p].contiguous()
+    leaves = [cpu[k].requires_grad_(True) for k in ("z", "cy", "c", "t", "mu")]
+
+    def one():
+        for q in leaves:
+            q.grad = None
+        x, y, cx, cy, ok, back = orc.trace_skew(cpu["x"], cpu["y"], cpu["z"], cpu["cx"], cpu["cy"], cpu["c"], cpu["t"],
+                                                cpu["mu"], cpu["mask"])
+        orc.compute_rms2d(x, y, ok).backward()
+    one()                                   # warm-up (first touch is ~15x slower)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[1]
+    try:
+        model = [ln.split(":")[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return dict(value=p * fw / med / 1e6, unit="M rays/s", cores=cores, kind="port",
+                sample=f"{p * fw} rays ({p} pupil points x {fw} field-wavelengths) of the same workload, fwd+bwd, "
+                       f"median of 3 after 1 warm-up, torch threads={cores}, cpu='{model}'")
+
+
+if __name__ == "__main__":
+    main()

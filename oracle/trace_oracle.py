@@ -38,6 +38,37 @@ EPS = 1e-6          # ray_tracing_lite.py:530,552
 ACOS_EPS = 1e-7     # ray_tracing_lite.py:644
 
 
+# ----------------------------------------------------------------------------------
+# Square root.  torch.sqrt on CPU tensors goes through MKL VML for large fp32 tensors and is
+# NOT correctly rounded there (measured in the build container: 0.7 % of uniform(0.5,1) inputs
+# are 1 ulp off, while short tensors take another code path and are exact), so the reference's
+# own fp32 output depends on the tensor size and cannot be reproduced bit for bit by IEEE-754
+# arithmetic.  The oracle therefore has two settings:
+#   ieee_sqrt=False : torch.sqrt  -> bit-exact with the reference fixtures (pins the oracle)
+#   ieee_sqrt=True  : correctly rounded sqrt (numpy) -> what the strict HIP kernels must match
+#                     bit for bit; it differs from the reference by <= a few ulp on a few % of rays
+# ----------------------------------------------------------------------------------
+class _IeeeSqrt(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v):
+        import numpy as np
+        out = torch.from_numpy(np.sqrt(v.detach().cpu().contiguous().numpy())).to(v.device)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return g / (2 * out)
+
+
+_IEEE = False
+
+
+def _sqrt(v):
+    return _IeeeSqrt.apply(v) if (_IEEE and v.dtype == torch.float32) else torch.sqrt(v)
+
+
 @dataclass
 class RayBundle:
     """Structure-of-arrays ray state in the local frame of the next surface vertex."""
@@ -63,7 +94,7 @@ def sphere_hit(c: torch.Tensor, r: RayBundle):
     tmp = c * m2 - 2 * mz
     cos2_i = r.cz ** 2 - c * tmp
     miss = cos2_i - EPS < 0
-    cos_i = torch.sqrt(torch.where(miss, torch.ones_like(cos2_i), cos2_i))
+    cos_i = _sqrt(torch.where(miss, torch.ones_like(cos2_i), cos2_i))
     d = e + tmp / (r.cz + cos_i)
     return miss, d, cos_i, cos2_i
 
@@ -96,14 +127,14 @@ def refract_sphere(c: torch.Tensor, mu: torch.Tensor, r: RayBundle, cos_i: torch
     """
     cos2_t = 1 - mu ** 2 * (1 - cos_i ** 2)
     tir = cos2_t - EPS < 0
-    cos_t = torch.sqrt(torch.where(tir, torch.ones_like(cos2_t), cos2_t))
+    cos_t = _sqrt(torch.where(tir, torch.ones_like(cos2_t), cos2_t))
     g = cos_t - mu * cos_i
     ncx = mu * r.cx - g * c * r.x
     ncy = mu * r.cy - g * c * r.y
     cz2 = 1 - (ncx ** 2 + ncy ** 2)
     fail = tir | (cz2 - EPS < 0)
     r.cx, r.cy = ncx, ncy
-    r.cz = torch.sqrt(torch.where(fail, torch.ones_like(cz2), cz2))
+    r.cz = _sqrt(torch.where(fail, torch.ones_like(cz2), cz2))
     return fail, cos2_t
 
 
@@ -117,17 +148,27 @@ def _flag_backward(r: RayBundle, dz: torch.Tensor, live: torch.Tensor, allow: bo
 
 
 def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate: bool = False,
-               allow_backward_rays: bool = True):
+               allow_backward_rays: bool = True, ieee_sqrt: bool = False):
     """Sequential trace through S spherical surfaces to the image plane (ref :594-675).
+    `ieee_sqrt`: see the note on _IeeeSqrt above (False = reference-exact).
 
     Shapes as in the reference: x,y [1|B,1|F,P,1|W]; z [B,1,1,1]; cx [1,1,1,1];
     cy [B,F,1,1]; c,t [B,1,1,1,S]; mu [B,1,1,W,S]; mask [B,1,1,1,S] (bool).
     Returns (x, y, cx, cy, ray_ok, ray_backward[, stacks]).
     """
+    global _IEEE
+    prev, _IEEE = _IEEE, bool(ieee_sqrt)
+    try:
+        return _trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays)
+    finally:
+        _IEEE = prev
+
+
+def _trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays):
     n_surf = t.shape[-1]
     cs, ts, mus, masks = (torch.unbind(a, dim=-1) for a in (c, t, mu, mask))
 
-    r = RayBundle(x, y, z, cx, cy, torch.sqrt(1 - cx ** 2 - cy ** 2),
+    r = RayBundle(x, y, z, cx, cy, _sqrt(1 - cx ** 2 - cy ** 2),
                   torch.ones_like(y, dtype=torch.bool), torch.zeros_like(y, dtype=torch.bool))
     stacks: Dict[str, List[torch.Tensor]] = {'z_RELU': [], 'theta_norm': [], 'theta_prime_norm': []}
     n_wave = mus[0].shape[-1]

@@ -46,6 +46,37 @@ def _stream_ptr(device) -> C.c_void_p:
 
 _ws_cache = {}
 
+# optional live timing of the C-ABI calls with events on the launch stream (bench.py)
+_timing = None
+
+
+def enable_timing(on: bool = True) -> None:
+    """Record a (start, stop) event pair around every tl_trace_fwd / tl_trace_bwd call."""
+    global _timing
+    _timing = {"fwd": [], "bwd": []} if on else None
+
+
+def timing_ms() -> dict:
+    """Mean GPU milliseconds per call since enable_timing(); synchronises the device."""
+    torch.cuda.synchronize()
+    return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None) for k, v in (_timing or {}).items()}
+
+
+class _Timed:
+    def __init__(self, key, dev):
+        self.key, self.dev = key, dev
+
+    def __enter__(self):
+        if _timing is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream(self.dev))
+
+    def __exit__(self, *exc):
+        if _timing is not None:
+            self.b.record(torch.cuda.current_stream(self.dev))
+            _timing[self.key].append((self.a, self.b))
+
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Per-(device, stream) scratch for the block partials; grows monotonically."""
@@ -103,7 +134,7 @@ class TraceFunction(torch.autograd.Function):
         else:
             fp, bp = [None] * 4, [None] * 2
         moments = torch.empty((F, TL_NMOM), dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _Timed("fwd", dev):
             rc = lib.tl_trace_fwd(C.byref(prob), *[_lib.ptr(b) for b in fp], *[_lib.ptr(b) for b in bp],
                                   None, _lib.ptr(moments), _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
         _lib.check(rc, "tl_trace_fwd")
@@ -142,7 +173,7 @@ class TraceFunction(torch.autograd.Function):
         gyin = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if need_yin else None
         gpar = torch.empty(2 * S + W * S + 1 + 2 * F, dtype=torch.float64, device=dev)
         g_c, g_t, g_mu, g_z, g_cx, g_cy = torch.split(gpar, [S, S, W * S, 1, F, F])
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _Timed("bwd", dev):
             rc = lib.tl_trace_bwd(C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd),
                                   _lib.ptr(gmd), _lib.ptr(g_c), _lib.ptr(g_t), _lib.ptr(g_mu), _lib.ptr(g_z),
                                   _lib.ptr(g_cx), _lib.ptr(g_cy), None, None, _lib.ptr(gxin), _lib.ptr(gyin),
