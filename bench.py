@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--mode", default=os.environ.get("TORCHOPTICS_AMD_MODE", "strict"), choices=["strict", "fast"])
     ap.add_argument("--log2-pupil", type=int, default=None, help="override log2 of pupil points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2-rays", type=int, default=21, help="log2 of the CPU-baseline sample (rays)")
+    ap.add_argument("--cpu-log2-rays", type=int, default=20, help="log2 of the CPU-baseline sample (rays)")
     return ap.parse_args()
 
 
@@ -209,8 +209,13 @@ def cpu_leg(args, meta, log2_rays):
     box's host cores on a bounded sample of the same workload: the first 2^log2_rays/(F*W) pupil
     points.  kind='port': the reference itself cannot travel to the GPU box."""
     from oracle import trace_oracle as orc
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("TL_CPU_THREADS", "32"))))
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle on {cores} threads ...", file=sys.stderr, flush=True)
     fw = meta["F"] * meta["W"]
     p = max(1, min(meta["P_local"], (1 << log2_rays) // fw))
     cpu = {k: v.detach().cpu() for k, v in args.items()}
@@ -223,12 +228,15 @@ def cpu_leg(args, meta, log2_rays):
         x, y, cx, cy, ok, back = orc.trace_skew(cpu["x"], cpu["y"], cpu["z"], cpu["cx"], cpu["cy"], cpu["c"], cpu["t"],
                                                 cpu["mu"], cpu["mask"])
         orc.compute_rms2d(x, y, ok).backward()
+    t0 = time.perf_counter()
     one()                                   # warm-up (first touch is ~15x slower)
+    print(f"[bench] cpu_baseline warm-up {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
     times = []
     for _ in range(3):
         t0 = time.perf_counter()
         one()
         times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline rep {times[-1]:.2f}s", file=sys.stderr, flush=True)
     med = sorted(times)[1]
     try:
         model = [ln.split(":")[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]

@@ -19,7 +19,12 @@ OBJ = os.path.join(ROOT, "build", "tltrace")
 LIB = os.path.join(HERE, "libtltrace.so")
 
 ARCH = "gfx950"
-COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc's SLP pass packs neighbouring scalar fp32 ops into v_pk_mul/add_f32,
+#   which on CDNA4 issue no faster than two scalar ops but need 64-bit-aligned register pairs
+#   (hundreds of extra v_mov, +49 VGPRs in the backward kernel): measured -11 % kernel time without it.
+# -DTL_BWD_WAVES=3: cap the backward kernel at 168 VGPRs -> 3 waves per SIMD (measured best of 1..4).
+COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+          "-fno-slp-vectorize", "-DTL_BWD_WAVES=3"]
 # strict: no FMA contraction, HIP's default correctly rounded fp32 sqrt / divide
 # fast  : contraction on; the kernels call v_rcp / v_sqrt explicitly
 UNITS = {
@@ -46,8 +51,18 @@ def _digest(paths, flags):
     return h.hexdigest()
 
 
-def build_library(force=False, verbose=True):
-    """Compile every translation unit and link libtltrace.so; returns its path."""
+def build_library(force=False, verbose=True, tag=None, extra_flags=()):
+    """Compile every translation unit and link libtltrace.so; returns its path.
+
+    `tag` / `extra_flags` build an experimental variant libtltrace_<tag>.so next to the default
+    one (used only by tools/ab_kernels.py for A/B timing)."""
+    global OBJ, LIB
+    obj_dir = OBJ if tag is None else OBJ + "_" + tag
+    lib_path = LIB if tag is None else os.path.join(HERE, f"libtltrace_{tag}.so")
+    return _build(obj_dir, lib_path, list(extra_flags), force, verbose)
+
+
+def _build(OBJ, LIB, extra_flags, force, verbose):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     deps = [os.path.normpath(os.path.join(CSRC, d)) for d in DEPS]
@@ -56,7 +71,7 @@ def build_library(force=False, verbose=True):
         spath = os.path.join(CSRC, src)
         opath = os.path.join(OBJ, src.replace(".hip", ".o"))
         stamp = opath + ".sha"
-        flags = COMMON + extra
+        flags = COMMON + extra + extra_flags
         dig = _digest([spath] + deps, flags)
         fresh = (not force and os.path.exists(opath) and os.path.exists(stamp)
                  and open(stamp).read() == dig)
