@@ -22,9 +22,8 @@ ARCH = "gfx950"
 # -fno-slp-vectorize: hipcc's SLP pass packs neighbouring scalar fp32 ops into v_pk_mul/add_f32,
 #   which on CDNA4 issue no faster than two scalar ops but need 64-bit-aligned register pairs
 #   (hundreds of extra v_mov, +49 VGPRs in the backward kernel): measured -11 % kernel time without it.
-# -DTL_BWD_WAVES=3: cap the backward kernel at 168 VGPRs -> 3 waves per SIMD (measured best of 1..4).
 COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-          "-fno-slp-vectorize", "-DTL_BWD_WAVES=3"]
+          "-fno-slp-vectorize"]
 # strict: no FMA contraction, HIP's default correctly rounded fp32 sqrt / divide
 # fast  : contraction on; the kernels call v_rcp / v_sqrt explicitly
 UNITS = {
