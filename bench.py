@@ -83,6 +83,19 @@ def workload(name, device, world, rank, log2_pupil):
     return args, meta, (tr, specs, lens, leaves, xy)
 
 
+def pmc_traffic(workload_name, mode, kernel, meta):
+    """HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
+    gfx950 FETCH correction applied) for this workload at its default size; None if not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            d = json.load(f)
+        if meta["P_local"] != (1 << 24) and workload_name == "cfg3":
+            return None
+        return d[workload_name][mode][kernel]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def flops_per_ray(S):
     """fp32 arithmetic operations per ray as written in csrc/tl_kernels.inc (mul, add/sub, sqrt, div,
     rcp each count 1; compares, selects, negations not counted; counted by hand):
@@ -172,8 +185,11 @@ def main():
     roofline = None
     if dom:
         roofline = dict(kernel="trace_bwd_kernel", bound="hbm", achieved=dom["hbm_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=dom["hbm_GBs"] / HBM_PEAK_GBS, traffic=None, launch_ms=dom["ms"],
-                        note="per-ray FMA kernel: the binding limit is the FP32 vector ALU, see roofline_valu")
+                        frac=dom["hbm_GBs"] / HBM_PEAK_GBS, traffic=pmc_traffic(a.workload, a.mode, "bwd", meta),
+                        launch_ms=dom["ms"], algorithmic_bytes_per_launch=rays_local * b_bwd,
+                        note="per-ray FMA kernel: the binding limit is the FP32 vector ALU, see roofline_valu; "
+                             "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes "
+                             "(profiles/r01_pmc_traffic.json), null for workloads not profiled")
     roofline_valu = None
     if dom:
         roofline_valu = dict(kernel="trace_bwd_kernel", bound="valu_fp32", achieved=dom["valu_TFLOPs"],
