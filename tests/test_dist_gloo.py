@@ -33,14 +33,14 @@ def _oracle_moments(x, y, ok):
                         okd.sum(dim=(1, 2)), z, z, z, z), dim=1)
 
 
-def _trace_loss(leaves_t, xy, group, n_per_field):
+def _trace_loss(leaves_t, xy, group, n_per_field, patch=setattr):
     """Assemble (package host logic) -> trace (oracle) -> compute_rms2d (package, sharded)."""
     import yaml_free_lenses as L
     import torchoptics_amd as ta
     from torchoptics_amd import lens_modeling as lm, ops, ray_tracing as rt
     from oracle import trace_oracle as orc
-    rt.trace_skew = lambda *a, mode=None, **k: orc.trace_skew(*a, **k)
-    ops.SpotMomentsFunction.apply = staticmethod(_oracle_moments)
+    patch(rt, "trace_skew", lambda *a, mode=None, **k: orc.trace_skew(*a, **k))
+    patch(ops.SpotMomentsFunction, "apply", staticmethod(_oracle_moments))
     d = L.PRESCRIPTIONS["cooke"]
     st = lm.Structure(stop_idx=np.array(d["stop_idx"]), sequence=np.array(d["sequence"]), default_device="cpu")
     lens = lm.Lens(st, *leaves_t)
@@ -89,7 +89,7 @@ def test_shard_range_covers_everything_once():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharded_loss_and_grads_equal_unsharded(tmp_path):
+def test_two_rank_sharded_loss_and_grads_equal_unsharded(tmp_path, monkeypatch):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     res = [torch.load(tmp_path / f"rank{r}.pt", weights_only=True) for r in range(2)]
@@ -102,7 +102,7 @@ def test_two_rank_sharded_loss_and_grads_equal_unsharded(tmp_path):
         from torchoptics_amd import ray_tracing as rt
         leaves = _leaves()
         xy = rt.circle_index_range(N_R, N_THETA, 0, N_R * N_THETA, "cpu")
-        loss, ok = _trace_loss(leaves, xy, None, None)
+        loss, ok = _trace_loss(leaves, xy, None, None, patch=monkeypatch.setattr)
         loss.backward()
     finally:
         torch.set_default_dtype(torch.float32)
