@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--mode", default=os.environ.get("TORCHOPTICS_AMD_MODE", "strict"), choices=["strict", "fast"])
     ap.add_argument("--log2-pupil", type=int, default=None, help="override log2 of pupil points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the secondary measurement of the other arithmetic mode")
     ap.add_argument("--cpu-log2-rays", type=int, default=20, help="log2 of the CPU-baseline sample (rays)")
     return ap.parse_args()
 
@@ -116,13 +119,17 @@ def main():
     if a.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     assert torch.cuda.is_available(), "bench.py needs an AMD GPU"
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group("gloo")
         group = dist.group.WORLD
 
     import torchoptics_amd as ta
@@ -150,21 +157,27 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        rms = step()
-    sync()
-    ops.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        rms = step()
-    sync()
-    dt = time.perf_counter() - t0
-    kern_ms = ops.timing_ms()
-    ops.enable_timing(False)
-    if group is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = tmax.item()
+    def timed(mode):
+        """W untimed warm-up steps, then exactly K steps between barrier+synchronize; max over ranks."""
+        ops.set_default_mode(mode)
+        for _ in range(a.warmup):
+            r = step()
+        sync()
+        ops.enable_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            r = step()
+        sync()
+        el = time.perf_counter() - t0
+        km = ops.timing_ms()
+        ops.enable_timing(False)
+        if group is not None:
+            tmax = torch.tensor([el], dtype=torch.float64, device="cpu" if a.backend == "gloo" else device)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            el = tmax.item()
+        return el, km, r
+
+    dt, kern_ms, rms = timed(a.mode)
 
     rays_local = meta["F"] * meta["W"] * meta["P_local"]
     rays_total = rays_local * world
@@ -197,9 +210,17 @@ def main():
     # whole-step algorithmic HBM rate (fwd + bwd bytes at the API boundary, SURVEY 8d headline)
     step_bytes = rays_total * (b_fwd + b_bwd)
 
-    cpu_baseline = None
+    other = None
+    if not a.no_other_mode:
+        om = "fast" if a.mode == "strict" else "strict"
+        odt, okm, orms = timed(om)
+        other = dict(arith_mode=om, value=rays_total * a.steps / odt / 1e6, unit="M rays/s", ms_per_step=odt / a.steps * 1e3,
+                     fwd_kernel_ms=okm.get("fwd"), bwd_kernel_ms=okm.get("bwd"), rms=float(orms.item()))
+        ops.set_default_mode(a.mode)
+
+    cpu_baseline, grad_check = None, None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu_baseline = cpu_leg(args, meta, a.cpu_log2_rays)
+        cpu_baseline, grad_check = cpu_leg(args, meta, a.cpu_log2_rays, a.mode)
 
     if rank == 0:
         out = {
@@ -213,6 +234,8 @@ def main():
                        "arith_mode": a.mode, "parallelism": f"pupil-sharded dp{world}", "rms": float(rms.item())},
             "roofline": roofline, "roofline_valu": roofline_valu, "kernels": kernels,
             "step_hbm_GBs": step_bytes / (dt / a.steps) / 1e9,
+            "grad_rel_err_vs_pytorch_autograd": grad_check,
+            "other_mode": other,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
@@ -220,10 +243,12 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def cpu_leg(args, meta, log2_rays):
+def cpu_leg(args, meta, log2_rays, mode):
     """The oracle (CPU restatement of the reference, eager PyTorch fp32 + autograd) timed on this
     box's host cores on a bounded sample of the same workload: the first 2^log2_rays/(F*W) pupil
-    points.  kind='port': the reference itself cannot travel to the GPU box."""
+    points.  kind='port': the reference itself cannot travel to the GPU box.  The same sample is then
+    traced by the HIP path and the gradients are compared (norm-relative, per parameter group)."""
+    import torchoptics_amd as ta
     from oracle import trace_oracle as orc
     try:
         cores = len(os.sched_getaffinity(0))
@@ -236,31 +261,67 @@ def cpu_leg(args, meta, log2_rays):
     p = max(1, min(meta["P_local"], (1 << log2_rays) // fw))
     cpu = {k: v.detach().cpu() for k, v in args.items()}
     cpu["x"], cpu["y"] = cpu["x"][:, :, :p].contiguous(), cpu["y"][:, :, :p].contiguous()
-    leaves = [cpu[k].requires_grad_(True) for k in ("z", "cy", "c", "t", "mu")]
+    names = ("z", "cy", "c", "t", "mu")
+    leaves = [cpu[k].requires_grad_(True) for k in names]
 
-    def one():
-        for q in leaves:
+    def one(dt=None, ieee=False):
+        src = cpu if dt is None else {k: (v.to(dt) if v.is_floating_point() else v) for k, v in cpu.items()}
+        lv = leaves if dt is None else [src[k].detach().requires_grad_(True) for k in names]
+        if dt is not None:
+            src.update(dict(zip(names, lv)))
+        for q in lv:
             q.grad = None
-        x, y, cx, cy, ok, back = orc.trace_skew(cpu["x"], cpu["y"], cpu["z"], cpu["cx"], cpu["cy"], cpu["c"], cpu["t"],
-                                                cpu["mu"], cpu["mask"])
+        x, y, cx, cy, ok, back = orc.trace_skew(src["x"], src["y"], src["z"], src["cx"], src["cy"], src["c"], src["t"],
+                                                src["mu"], src["mask"], ieee_sqrt=ieee)
         orc.compute_rms2d(x, y, ok).backward()
+        return [q.grad.clone() for q in lv]
     t0 = time.perf_counter()
     one()                                   # warm-up (first touch is ~15x slower)
     print(f"[bench] cpu_baseline warm-up {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
     times = []
     for _ in range(3):
         t0 = time.perf_counter()
-        one()
+        g32 = one()
         times.append(time.perf_counter() - t0)
         print(f"[bench] cpu_baseline rep {times[-1]:.2f}s", file=sys.stderr, flush=True)
     med = sorted(times)[1]
+    g64 = one(torch.float64)
+    g32i = one(None, ieee=True)
+    # the same sample through the HIP path
+    dev = args["x"].device
+    gl = [args[k].detach().clone().requires_grad_(True) for k in names]
+    ga = dict(args)
+    ga.update(dict(zip(names, gl)))
+    x, y, cx, cy, ok, back = ta.trace_skew(args["x"][:, :, :p].contiguous(), args["y"][:, :, :p].contiguous(), ga["z"],
+                                           ga["cx"], ga["cy"], ga["c"], ga["t"], ga["mu"], ga["mask"], mode=mode)
+    ta.compute_rms2d(x, y, ok).backward()
+
+    def rel(a, b):
+        return float(((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300)).item())
+    gc = {}
+    for k, q, r32, r32i, r64 in zip(names, gl, g32, g32i, g64):
+        gc[k] = dict(vs_fp32_autograd_ieee_sqrt=rel(q.grad.cpu(), r32i), vs_fp32_autograd_mkl_sqrt=rel(q.grad.cpu(), r32),
+                     vs_fp64_autograd=rel(q.grad.cpu(), r64), fp32_autograd_mkl_vs_ieee=rel(r32, r32i),
+                     fp32_autograd_mkl_vs_fp64=rel(r32, r64))
+    lens_groups = ("c", "t", "mu")
+    grad_check = dict(sample_rays=p * fw, arith_mode=mode, per_group=gc,
+                      max_vs_fp32_autograd=max(gc[k]["vs_fp32_autograd_ieee_sqrt"] for k in lens_groups),
+                      max_vs_fp32_autograd_mkl_sqrt=max(gc[k]["vs_fp32_autograd_mkl_sqrt"] for k in lens_groups),
+                      max_vs_fp64_autograd=max(gc[k]["vs_fp64_autograd"] for k in lens_groups),
+                      pytorch_fp32_self_noise=max(gc[k]["fp32_autograd_mkl_vs_ieee"] for k in lens_groups),
+                      note="norm-relative error per parameter group, max over the lens parameters c, t, mu. "
+                           "PyTorch fp32 autograd = the CPU oracle (bit-exact with the reference on CPU). torch.sqrt on "
+                           "CPU (MKL) is up to 1 ulp off; 'ieee_sqrt' is the same autograd graph with a correctly "
+                           "rounded sqrt. pytorch_fp32_self_noise = how far those two PyTorch runs are from each "
+                           "other: the floor below which 'vs PyTorch autograd' is not defined for this lens")
     try:
         model = [ln.split(":")[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    return dict(value=p * fw / med / 1e6, unit="M rays/s", cores=cores, kind="port",
+    base = dict(value=p * fw / med / 1e6, unit="M rays/s", cores=cores, kind="port",
                 sample=f"{p * fw} rays ({p} pupil points x {fw} field-wavelengths) of the same workload, fwd+bwd, "
                        f"median of 3 after 1 warm-up, torch threads={cores}, cpu='{model}'")
+    return base, grad_check
 
 
 if __name__ == "__main__":
