@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 3
+#define TL_ABI_VERSION 4
 #define TL_MAX_SURFACES 32       /* rows per lens the backward kernels are built for */
 #define TL_NMOM 8                /* spot moments per field, see tl_trace_fwd */
 #define TL_MAX_POLY 4            /* even aspheric terms a4,a6,a8,a10 */
@@ -64,11 +64,16 @@ typedef struct tl_problem {
     const float *c, *t;          /* [S]   curvature, thickness (:121-122)                    */
     const float *mu;             /* [W,S] n_before/n_after per wavelength (:123)             */
     const uint8_t *mask;         /* [S]   non-padding rows (:124)                            */
-    /* ---- aspheric extension (not in the reference; NULL = all-spherical) ---- */
-    const float *kappa;          /* [S]   conic constant, 0 = sphere                         */
+    /* ---- aspheric extension (not in the reference; all three NULL = all-spherical) ----
+       sag(rho) = c rho/(1+sqrt(1-(1+kappa) c^2 rho)) + a4 rho^2 + a6 rho^3 + a8 rho^4 + a10 rho^5,
+       rho = x^2+y^2; rows with surf_kind 1 are intersected by Newton iteration from the closed-form
+       sphere hit and refracted at the aspheric normal; rows with surf_kind 0 take the reference's
+       closed form and ignore kappa / poly. */
+    const float *kappa;          /* [S]   conic constant                                     */
     const float *poly;           /* [S,TL_MAX_POLY] a4,a6,a8,a10                             */
     const uint8_t *surf_kind;    /* [S]   0 = closed-form sphere, 1 = Newton asphere         */
-    const float *n_index;        /* [W,S+1] refractive indices for OPD, or NULL              */
+    const float *n_index;        /* [W,S+1] refractive indices (entry 0 = object space); only
+                                    read when tl_trace_fwd is asked for `opd`                 */
 } tl_problem;
 
 int         tl_version(void);            /* == TL_ABI_VERSION */
@@ -84,7 +89,9 @@ size_t tl_workspace_bytes(const tl_problem *p);
  * reset_bad_rays :574-591, apply_snell_spherical :548-571, image-plane transfer :659-663).
  *   x,y,cx,cy : [F,W,P] float  (any may be NULL = not wanted)
  *   ok,back   : [F,W,P] uint8  (nullable)
- *   opd       : [F,W,P] float  optical path length, needs p->n_index (nullable; extension)
+ *   opd       : [F,W,P] float  optical path length sum_k n_k d_k + n_S d_image from the pupil plane
+ *               to the image plane, 0 for failed rays; needs p->n_index (nullable; extension,
+ *               forward only: no gradient flows through it)
  *   moments   : [F,TL_NMOM] double (nullable), per field over (w,p):
  *               0 sum y | 1 sum ok*y | 2 sum ok*y^2 | 3 sum ok | 4 sum x | 5 sum ok*x |
  *               6 sum ok*x^2 | 7 sum back

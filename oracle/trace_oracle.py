@@ -213,6 +213,127 @@ def _trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays)
     return r.x, r.y, r.cx, r.cy, r.ok, r.back
 
 
+# ----------------------------------------------------------------------------------
+# EXTENSION (not in the reference; PARITY UNPINNED by the reference): aspheric surfaces with a
+# Newton intersection, vector Snell refraction at the aspheric normal, and optical path length.
+#
+#   sag(rho) = c rho / (1 + sqrt(1 - (1+kappa) c^2 rho)) + a4 rho^2 + a6 rho^3 + a8 rho^4 + a10 rho^5,
+#   rho = x^2 + y^2.
+#
+# Rows with kind == 0 go through sphere_hit / refract_sphere above, untouched, so an all-spherical
+# call of trace_skew_general is the reference algorithm.  This file is the DEFINITION the HIP
+# kernels are tested against for kind == 1 rows: forward by value, backward by this autograd graph
+# evaluated in fp64 (Newton unrolled for a fixed number of iterations, i.e. exact to rounding).
+# ----------------------------------------------------------------------------------
+NEWTON_ITERS = 8        # oracle: always this many (no early exit); kernels: at most this many
+NEWTON_TOL = 1e-6       # fp32 convergence: |F| <= NEWTON_TOL * (1 + |z_hit|)   [mm]
+
+
+def _sag_terms(c, kappa, a, rho):
+    """Returns (sag, dsag/drho, conic-domain-violated)."""
+    q2 = 1 - (1 + kappa) * c * c * rho
+    bad = q2 - EPS < 0
+    q = _sqrt(torch.where(bad, torch.ones_like(q2), q2))
+    sag = c * rho / (1 + q) + rho * rho * (a[0] + rho * (a[1] + rho * (a[2] + rho * a[3])))
+    dsag = c / (2 * q) + rho * (2 * a[0] + rho * (3 * a[1] + rho * (4 * a[2] + rho * (5 * a[3]))))
+    return sag, dsag, bad
+
+
+def asphere_hit(c, kappa, a, r: RayBundle):
+    """Newton iteration on the ray parameter s from the closed-form sphere hit.
+
+    Returns (miss, s, X, Y, dsag, rho): hit point (X, Y), d sag / d rho there.
+    """
+    miss0, d0, _, _ = sphere_hit(c, r)
+    s = torch.where(miss0, torch.zeros_like(d0), d0)
+    tol = NEWTON_TOL if s.dtype == torch.float32 else 1e-13
+    for _ in range(NEWTON_ITERS):
+        X, Y = r.x + s * r.cx, r.y + s * r.cy
+        rho = X * X + Y * Y
+        sag, dsag, _ = _sag_terms(c, kappa, a, rho)
+        F = (r.z + s * r.cz) - sag
+        Fp = r.cz - dsag * (2 * (X * r.cx + Y * r.cy))
+        s = s - F / Fp
+    X, Y = r.x + s * r.cx, r.y + s * r.cy
+    rho = X * X + Y * Y
+    sag, dsag, bad = _sag_terms(c, kappa, a, rho)
+    zhit = r.z + s * r.cz
+    conv = torch.abs(zhit - sag) <= tol * (1 + torch.abs(zhit))
+    return miss0 | bad | ~conv, s, X, Y, dsag, rho
+
+
+def refract_general(mu, r: RayBundle, dsag, rho):
+    """Vector Snell at the aspheric normal n = (-m X, -m Y, 1)/sqrt(1 + m^2 rho), m = 2 dsag/drho.
+    r.x, r.y are already the hit point.  Updates r.cx, r.cy, r.cz; returns (fail, cos2_i, cos2_t)."""
+    m = 2 * dsag
+    inv_n = 1 / _sqrt(1 + m * m * rho)
+    nx, ny, nz = -(m * r.x) * inv_n, -(m * r.y) * inv_n, inv_n
+    cos_i = (r.cx * nx + r.cy * ny) + r.cz * nz
+    cos2_t = 1 - mu ** 2 * (1 - cos_i ** 2)
+    tir = cos2_t - EPS < 0
+    cos_t = _sqrt(torch.where(tir, torch.ones_like(cos2_t), cos2_t))
+    g = cos_t - mu * cos_i
+    ncx = mu * r.cx + g * nx
+    ncy = mu * r.cy + g * ny
+    cz2 = 1 - (ncx ** 2 + ncy ** 2)
+    fail = tir | (cz2 - EPS < 0)
+    r.cx, r.cy = ncx, ncy
+    r.cz = _sqrt(torch.where(fail, torch.ones_like(cz2), cz2))
+    return fail, cos_i * cos_i, cos2_t
+
+
+def trace_skew_general(x, y, z, cx, cy, c, t, mu, mask, kappa=None, poly=None, kind=None,
+                       allow_backward_rays: bool = True, n_index=None, ieee_sqrt: bool = False):
+    """trace_skew with optional aspheric rows and optical path length.
+
+    kappa [S], poly [S,4] (a4, a6, a8, a10), kind: sequence of S ints (0 sphere closed form,
+    1 Newton asphere); n_index [1,1,1,W,S+1] refractive indices (index 0 = object space) for OPD.
+    Returns (x, y, cx, cy, ray_ok, ray_backward, opd) with opd = sum_k n_k d_k + n_S dist_image
+    (None when n_index is None).  Dead rays: opd = 0.
+    """
+    global _IEEE
+    prev, _IEEE = _IEEE, bool(ieee_sqrt)
+    try:
+        n_surf = t.shape[-1]
+        cs, ts, mus, masks = (torch.unbind(a, dim=-1) for a in (c, t, mu, mask))
+        kind = [0] * n_surf if kind is None else [int(k) for k in kind]
+        ns = None if n_index is None else torch.unbind(n_index, dim=-1)
+        r = RayBundle(x, y, z, cx, cy, _sqrt(1 - cx ** 2 - cy ** 2),
+                      torch.ones_like(y, dtype=torch.bool), torch.zeros_like(y, dtype=torch.bool))
+        opd = None if ns is None else torch.zeros_like(y)
+        for k in range(n_surf):
+            if kind[k] == 0:
+                miss, d, cos_i, _ = sphere_hit(cs[k], r)
+                dz = advance(r, d)
+            else:
+                miss, d, X, Y, dsag, rho = asphere_hit(cs[k], kappa[k], poly[k], r)
+                dz = d * r.cz
+                r.x, r.y, r.z = X, Y, r.z + dz
+            r.ok = r.ok & ~miss
+            retire_dead(r)
+            if kind[k] == 0:
+                fail, _ = refract_sphere(cs[k], mus[k], r, cos_i)
+            else:
+                fail, _, _ = refract_general(mus[k], r, dsag, rho)
+            if k > 0:
+                _flag_backward(r, dz, r.ok & masks[k - 1], allow_backward_rays)
+            r.ok = r.ok & ~fail
+            retire_dead(r)
+            r.z = r.z - ts[k]
+            if opd is not None:
+                opd = torch.where(r.ok, opd + ns[k] * d, torch.zeros_like(opd + ns[k] * d))
+        dz = -r.z
+        dist = dz / r.cz
+        r.x = r.x + dist * r.cx
+        r.y = r.y + dist * r.cy
+        if opd is not None:
+            opd = torch.where(r.ok, opd + ns[-1] * dist, torch.zeros_like(opd + ns[-1] * dist))
+        _flag_backward(r, dz, r.ok & masks[-1], allow_backward_rays)
+        return r.x, r.y, r.cx, r.cy, r.ok, r.back, opd
+    finally:
+        _IEEE = prev
+
+
 def compute_rms2d(x, y, ray_ok):
     """y-only RMS spot for sample 0, averaged over fields (ref :678-702).
 

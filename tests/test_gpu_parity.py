@@ -90,9 +90,11 @@ def test_backward_vs_reference_autograd(ta, case):
     for n, (e32, e64, ref_noise) in report.items():
         if n == "cx":      # d/dcx is pure rounding noise for meridional fans (value ~1e-10)
             continue
-        # lens parameters (sums over all rays): 1e-5.  Per-ray input gradients d/dx, d/dy are single
-        # fp32 chains with no averaging: 3e-5, or within the fp32 reference's own distance from fp64.
-        tol = 3e-5 if n in ("x", "y") else 1e-5
+        # lens parameters c, t, mu: 1e-5.  Launch conditions: per-ray d/dx, d/dy are single fp32
+        # chains with no averaging, and d/dz, d/dcy are small residuals of large per-ray terms
+        # (the seeds are mean-free and d y/d z is nearly the same for every ray): 3e-5, or within the
+        # fp32 reference's own distance from fp64.
+        tol = 1e-5 if n in ("c", "t", "mu") else 3e-5
         assert e32 <= tol or e64 <= max(tol, ref_noise), f"{case} d/d{n}: vs fp32 {e32:.2e}, vs fp64 {e64:.2e}"
         assert e64 <= 3e-5 + ref_noise, f"{case} d/d{n}: vs fp64 {e64:.2e}"
 

@@ -1,0 +1,91 @@
+"""
+CPU self-checks of the oracle's aspheric extension (oracle.trace_skew_general).  The reference
+has no aspheres, so nothing here is pinned by it (PARITY UNPINNED): the checks are internal
+consistency -- the all-spherical general path IS the reference path, Newton on a sphere finds
+the closed-form hit, autograd agrees with finite differences in fp64, OPD obeys Fermat-style
+sanity -- so that the definition the HIP kernels are tested against is itself trustworthy.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import trace_oracle as orc
+
+IN = ("in_x", "in_y", "in_z", "in_cx", "in_cy", "in_c", "in_t", "in_mu")
+
+
+def _case(dtype=torch.float32):
+    g = load_golden("G4_tessar_32x32")
+    return [torch.from_numpy(g[n]).to(dtype) for n in IN], torch.from_numpy(g["in_mask"])
+
+
+def asphere_params(S, dtype=torch.float32):
+    kap = torch.zeros(S, dtype=dtype)
+    pol = torch.zeros(S, 4, dtype=dtype)
+    kap[0], kap[5] = -0.8, 0.5
+    pol[0, 0], pol[0, 1], pol[5, 0], pol[5, 2] = 2e-5, -3e-7, -4e-5, 1e-9
+    kind = [0] * S
+    kind[0] = kind[5] = 1
+    return kap, pol, kind
+
+
+def test_all_spherical_general_path_is_the_reference_path():
+    ins, mask = _case()
+    a = orc.trace_skew(*ins, mask)
+    b = orc.trace_skew_general(*ins, mask)
+    assert all(torch.equal(p, q) for p, q in zip(a, b[:6])) and b[6] is None
+
+
+def test_newton_on_a_sphere_finds_the_closed_form_hit():
+    ins, mask = _case(torch.float64)
+    S = ins[5].shape[-1]
+    kind = [1] * S
+    kind[4] = 0                      # the flat stop stays closed-form
+    a = orc.trace_skew(*ins, mask)
+    b = orc.trace_skew_general(*ins, mask, torch.zeros(S, dtype=torch.float64), torch.zeros(S, 4, dtype=torch.float64), kind)
+    assert torch.equal(a[4], b[4])
+    assert (a[0] - b[0]).abs().max() < 1e-11 and (a[1] - b[1]).abs().max() < 1e-11
+
+
+def test_autograd_of_aspheric_coefficients_matches_finite_differences():
+    ins, mask = _case(torch.float64)
+    S = ins[5].shape[-1]
+    kap, pol, kind = asphere_params(S, torch.float64)
+    kap.requires_grad_(True)
+    pol.requires_grad_(True)
+    c = ins[5].clone().requires_grad_(True)
+
+    def loss():
+        o = orc.trace_skew_general(ins[0], ins[1], ins[2], ins[3], ins[4], c, ins[6], ins[7], mask, kap, pol, kind)
+        return orc.compute_rms2d(o[0], o[1], o[4])
+    loss().backward()
+    for tens, idx, h in ((kap, (0,), 1e-6), (kap, (5,), 1e-6), (pol, (0, 0), 1e-9), (pol, (0, 1), 1e-10),
+                         (pol, (5, 2), 1e-13), (c, (0, 0, 0, 0, 0), 1e-7), (c, (0, 0, 0, 0, 5), 1e-7)):
+        with torch.no_grad():
+            base = tens[idx].item()
+            tens[idx] = base + h
+            lp = loss().item()
+            tens[idx] = base - h
+            lm_ = loss().item()
+            tens[idx] = base
+        fd = (lp - lm_) / (2 * h)
+        assert abs(tens.grad[idx].item() - fd) <= 2e-5 * abs(fd) + 1e-12, (idx, tens.grad[idx].item(), fd)
+
+
+def test_optical_path_length_is_consistent():
+    ins, mask = _case(torch.float64)
+    S = ins[5].shape[-1]
+    mu = ins[7]                                            # [1,1,1,W,S] = n_before / n_after
+    n = torch.ones(1, 1, 1, mu.shape[3], S + 1, dtype=torch.float64)
+    for k in range(S):
+        n[..., k + 1] = n[..., k] / mu[..., k]
+    o = orc.trace_skew_general(*ins, mask, n_index=n)
+    opd = o[6]
+    assert opd.shape == o[0].shape and torch.isfinite(opd).all()
+    # geometric length <= optical length (n >= 1), and the on-axis chief ray of field 0 runs straight
+    # down the axis: its path from the pupil plane is  -z_pupil + sum_k n_k t_k (last t = image distance)
+    axis = opd[0, 0, 0, :]                                  # pupil point 0 of the circular grid is r = 0
+    want = -ins[2].reshape(()) * n[0, 0, 0, :, 0] + (n[0, 0, 0, :, 1:] * ins[6].reshape(1, S)).sum(dim=1)
+    assert torch.allclose(axis, want, rtol=0, atol=1e-9)
+    assert (opd[o[4]] > 0).all() and (opd[~o[4]] == 0).all()

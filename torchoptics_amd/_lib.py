@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtltrace.so")
 
-TL_ABI_VERSION = 3
+TL_ABI_VERSION = 4
 TL_NMOM = 8
 TL_MAX_SURFACES = 32
 TL_MAX_POLY = 4

@@ -69,7 +69,8 @@ int check_problem(const tl_problem *p)
         return fail(TL_EINVAL, "a required device pointer of tl_problem is NULL");
     if (p->mode != TL_MODE_STRICT && p->mode != TL_MODE_FAST) return fail(TL_EINVAL, "unknown mode");
     if ((p->cx_stride | 1) != 1 || (p->cy_stride | 1) != 1) return fail(TL_EINVAL, "cx/cy stride must be 0 or 1");
-    if (p->surf_kind || p->kappa || p->poly) return fail(TL_EINVAL, "aspheric rows are not supported by this build");
+    if ((p->surf_kind != nullptr) != (p->kappa != nullptr) || (p->surf_kind != nullptr) != (p->poly != nullptr))
+        return fail(TL_EINVAL, "surf_kind, kappa and poly must be given together (or all NULL)");
     return TL_OK;
 }
 
@@ -115,10 +116,10 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
                                                             int W, int S, int nbx, double *__restrict__ g_c,
                                                             double *__restrict__ g_t, double *__restrict__ g_mu,
                                                             double *__restrict__ g_z, double *__restrict__ g_cx,
-                                                            double *__restrict__ g_cy)
+                                                            double *__restrict__ g_cy, int ncol,
+                                                            double *__restrict__ g_kappa, double *__restrict__ g_poly)
 {
     __shared__ double sm[kBlock];
-    const int ncol = 3 * NS + 3;
     int b = blockIdx.x;
     double *out;
     int col, f0 = 0, nf = F, w0 = 0, nw = W;
@@ -127,7 +128,9 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
     else if ((b -= S) < W * S) { const int w = b / S, k = b % S; col = 2 * NS + k; w0 = w; nw = 1; out = g_mu + b; }
     else if ((b -= W * S) < 1) { col = 3 * NS; out = g_z; }
     else if ((b -= 1) < F) { col = 3 * NS + 1; f0 = b; nf = 1; out = g_cx + b; }
-    else { b -= F; col = 3 * NS + 2; f0 = b; nf = 1; out = g_cy + b; }
+    else if ((b -= F) < F) { col = 3 * NS + 2; f0 = b; nf = 1; out = g_cy + b; }
+    else if ((b -= F) < S) { col = 3 * NS + 3 + b; out = g_kappa + b; }                 // aspheric rows only
+    else { b -= S; col = 4 * NS + 3 + b; out = g_poly + b; }                             // b = 4k + j
     const double s = sum_rows(part, ncol, col, W, nbx, f0, nf, w0, nw, sm);
     if (threadIdx.x == 0) *out = s;
 }
@@ -208,7 +211,7 @@ size_t tl_workspace_bytes(const tl_problem *p)
     const int ns = tl_bwd_bucket(p->S);
     const size_t fw = (size_t)p->F * p->W;
     const size_t a = fw * pf.nbx * TL_NMOM * sizeof(double);
-    const size_t b = fw * pb.nbx * (size_t)(3 * (ns < 0 ? TL_MAX_SURFACES : ns) + 3) * sizeof(double);
+    const size_t b = fw * pb.nbx * (size_t)tl_bwd_row(ns < 0 ? TL_MAX_SURFACES : ns, p->surf_kind != nullptr) * sizeof(double);
     return (a > b ? a : b) + 256;
 }
 
@@ -217,7 +220,7 @@ int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, 
 {
     int rc = check_problem(p);
     if (rc) return rc;
-    if (opd) return fail(TL_EINVAL, "opd output is not supported by this build");
+    if (opd && !p->n_index) return fail(TL_EINVAL, "the opd output needs tl_problem.n_index");
     if (p->P == 0) {
         if (moments) {
             hipError_t e = hipMemsetAsync(moments, 0, (size_t)p->F * TL_NMOM * sizeof(double), (hipStream_t)stream);
@@ -235,8 +238,10 @@ int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, 
         part = (double *)workspace;
     }
     hipStream_t st = (hipStream_t)stream;
-    int herr = (p->mode == TL_MODE_FAST) ? tl_fast::api_fwd(*p, x, y, cx, cy, ok, back, part, pl.nbx, pl.R, st)
-                                         : tl_strict::api_fwd(*p, x, y, cx, cy, ok, back, part, pl.nbx, pl.R, st);
+    tl_problem q = *p;
+    if (!opd) q.n_index = nullptr;          // the kernel accumulates the path length only when asked
+    int herr = (p->mode == TL_MODE_FAST) ? tl_fast::api_fwd(q, x, y, cx, cy, ok, back, opd, part, pl.nbx, pl.R, st)
+                                         : tl_strict::api_fwd(q, x, y, cx, cy, ok, back, opd, part, pl.nbx, pl.R, st);
     if (herr) return hip_fail(herr, "trace_fwd_kernel launch");
     if (moments) {
         hipLaunchKernelGGL(reduce_moments_kernel, dim3(p->F * TL_NMOM), dim3(kBlock), 0, st, part, moments, p->W, pl.nbx);
@@ -254,7 +259,8 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
     int rc = check_problem(p);
     if (rc) return rc;
     if (!g_c || !g_t || !g_mu || !g_z || !g_cx || !g_cy) return fail(TL_EINVAL, "a parameter-gradient output is NULL");
-    if (g_kappa || g_poly) return fail(TL_EINVAL, "aspheric gradients are not supported by this build");
+    if ((g_kappa || g_poly) && !p->surf_kind) return fail(TL_EINVAL, "g_kappa / g_poly need aspheric rows (surf_kind)");
+    if (p->surf_kind && (!g_kappa || !g_poly)) return fail(TL_EINVAL, "aspheric rows need g_kappa and g_poly outputs");
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSetDevice(p->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
@@ -262,22 +268,25 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
         const size_t S = p->S;
         if ((e = hipMemsetAsync(g_c, 0, S * 8, st)) || (e = hipMemsetAsync(g_t, 0, S * 8, st)) ||
             (e = hipMemsetAsync(g_mu, 0, S * p->W * 8, st)) || (e = hipMemsetAsync(g_z, 0, 8, st)) ||
-            (e = hipMemsetAsync(g_cx, 0, (size_t)p->F * 8, st)) || (e = hipMemsetAsync(g_cy, 0, (size_t)p->F * 8, st)))
+            (e = hipMemsetAsync(g_cx, 0, (size_t)p->F * 8, st)) || (e = hipMemsetAsync(g_cy, 0, (size_t)p->F * 8, st)) ||
+            (g_kappa && (e = hipMemsetAsync(g_kappa, 0, S * 8, st))) || (g_poly && (e = hipMemsetAsync(g_poly, 0, S * 32, st))))
             return hip_fail(e, "hipMemsetAsync(grads)");
         return TL_OK;
     }
     const Plan pl = plan_bwd(p);
     const int ns = tl_bwd_bucket(p->S);
-    const size_t need = (size_t)p->F * p->W * pl.nbx * (size_t)(3 * ns + 3) * sizeof(double);
+    const bool asph = p->surf_kind != nullptr;
+    const int ncol = tl_bwd_row(ns, asph);
+    const size_t need = (size_t)p->F * p->W * pl.nbx * (size_t)ncol * sizeof(double);
     if (!workspace || workspace_bytes < need) return fail(TL_EWORKSPACE, "workspace too small for tl_trace_bwd");
     double *part = (double *)workspace;
     int herr = (p->mode == TL_MODE_FAST)
                    ? tl_fast::api_bwd(*p, gx, gy, gcx, gcy, g_moments, g_x_in, g_y_in, part, pl.nbx, pl.R, st)
                    : tl_strict::api_bwd(*p, gx, gy, gcx, gcy, g_moments, g_x_in, g_y_in, part, pl.nbx, pl.R, st);
     if (herr) return hip_fail(herr, "trace_bwd_kernel launch");
-    const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F;
+    const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0);
     hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout), dim3(kBlock), 0, st, part, ns, p->F, p->W, p->S, pl.nbx, g_c,
-                       g_t, g_mu, g_z, g_cx, g_cy);
+                       g_t, g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly);
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");
     return TL_OK;

@@ -166,9 +166,27 @@ class Lens:
     t: torch.Tensor
     nd: torch.Tensor
     v: torch.Tensor
+    # aspheric extension (not in the reference): conic constant per row and even polynomial terms
+    # a4, a6, a8, a10 per row; 1-D / 2-D flat forms over the real rows, or padded [lens,row] / [lens,row,4]
+    kappa: Optional[torch.Tensor] = None
+    poly: Optional[torch.Tensor] = None
 
     def __post_init__(self):
         st = self.structure
+        if (self.kappa is None) != (self.poly is None):
+            n_rows = int(st.mask.sum())
+            ref = self.kappa if self.kappa is not None else self.poly
+            if self.kappa is None:
+                self.kappa = torch.zeros(n_rows, dtype=ref.dtype, device=ref.device)
+            else:
+                self.poly = torch.zeros(n_rows, 4, dtype=ref.dtype, device=ref.device)
+        if self.kappa is not None:
+            if self.kappa.dim() == 1:
+                self.kappa = _pad_from_flat(self.kappa, st.mask_torch, 0.0)
+            if self.poly.dim() == 2:                 # flat [rows, 4] -> padded [lens, row, 4]
+                flat = self.poly
+                base = torch.zeros((*st.mask.shape, 4), dtype=flat.dtype, device=st.mask_torch.device)
+                self.poly = base.masked_scatter(st.mask_torch[..., None].expand_as(base), flat)
         if self.c.dim() == 1:
             self.c = _pad_from_flat(self.c, st.mask_torch, 0.0)
         if self.t.dim() == 1:
@@ -181,26 +199,37 @@ class Lens:
     def __len__(self):
         return len(self.structure)
 
+    def _asph(self, fn):
+        return (None, None) if self.kappa is None else (fn(self.kappa), fn(self.poly))
+
     def scale(self, factor) -> "Lens":
+        if self.kappa is not None:
+            powers = torch.tensor([3., 5., 7., 9.], dtype=self.poly.dtype, device=self.poly.device)
+            return Lens(self.structure, self.c / factor, self.t * factor, self.nd, self.v, self.kappa,
+                        self.poly / factor ** powers)
         return Lens(self.structure, self.c / factor, self.t * factor, self.nd, self.v)
 
     def up_to_stop(self) -> "Lens":
         st = self.structure.up_to_stop()
         n = st.mask.shape[1]
+        kap, pol = self._asph(lambda a: a[:, :n][st.mask_torch])
         return Lens(st, self.c[:, :n][st.mask_torch], self.t[:, :n][st.mask_torch],
-                    self.nd[:, :n][st.mask_G_torch], self.v[:, :n][st.mask_G_torch])
+                    self.nd[:, :n][st.mask_G_torch], self.v[:, :n][st.mask_G_torch], kap, pol)
 
     def __getitem__(self, index) -> "Lens":
         index = slice(index, index + 1) if isinstance(index, int) else index
         st = self.structure[index]
         n = st.mask.shape[1]
-        return Lens(st, self.c[index, :n], self.t[index, :n], self.nd[index, :n], self.v[index, :n])
+        kap, pol = self._asph(lambda a: a[index, :n])
+        return Lens(st, self.c[index, :n], self.t[index, :n], self.nd[index, :n], self.v[index, :n], kap, pol)
 
     def detach(self) -> "Lens":
-        return Lens(self.structure, self.c.detach(), self.t.detach(), self.nd.detach(), self.v.detach())
+        kap, pol = self._asph(lambda a: a.detach())
+        return Lens(self.structure, self.c.detach(), self.t.detach(), self.nd.detach(), self.v.detach(), kap, pol)
 
     def to(self, dtype) -> "Lens":
-        return Lens(self.structure, self.c.to(dtype), self.t.to(dtype), self.nd.to(dtype), self.v.to(dtype))
+        kap, pol = self._asph(lambda a: a.to(dtype))
+        return Lens(self.structure, self.c.to(dtype), self.t.to(dtype), self.nd.to(dtype), self.v.to(dtype), kap, pol)
 
     def double(self) -> "Lens":
         return self.to(torch.float64)

@@ -88,7 +88,8 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode):
+def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa=None, poly=None, kind_u8=None,
+             n_index=None):
     F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
     p = tl_problem()
     p.F, p.P, p.W, p.S = F, P, W, c.numel()
@@ -102,7 +103,11 @@ def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode):
     p.cx_stride = 0 if cx.numel() == 1 else 1
     p.cy_stride = 0 if cy.numel() == 1 else 1
     p.c, p.t, p.mu, p.mask = c.data_ptr(), t.data_ptr(), mu.data_ptr(), mask_u8.data_ptr()
-    p.kappa = p.poly = p.surf_kind = p.n_index = None
+    asph = kind_u8 is not None
+    p.kappa = kappa.data_ptr() if asph else None
+    p.poly = poly.data_ptr() if asph else None
+    p.surf_kind = kind_u8.data_ptr() if asph else None
+    p.n_index = n_index.data_ptr() if n_index is not None else None
     return p
 
 
@@ -112,10 +117,14 @@ def _fwp(t):
 
 
 class TraceFunction(torch.autograd.Function):
-    """(x, y, cx, cy, ok, back, moments) = trace(x_in, y_in, z, cx, cy, c, t, mu)."""
+    """(x, y, cx, cy, ok, back, moments, opd) = trace(x_in, y_in, z, cx, cy, c, t, mu[, kappa, poly]).
+
+    kappa [S], poly [S,4], kind_u8 [S] are None for an all-spherical lens (the reference's case);
+    n_index [W,S+1] is only needed for the optical path length output (`want_opd`)."""
 
     @staticmethod
-    def forward(ctx, x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, want_rays):
+    def forward(ctx, x_e, y_e, z, cx, cy, c, t, mu, kappa, poly, mask_u8, kind_u8, n_index, allow_back, mode,
+                want_rays, want_opd):
         for name, ten in (("x", x_e), ("y", y_e), ("z", z), ("cx", cx), ("cy", cy), ("c", c), ("t", t),
                           ("mu", mu), ("mask", mask_u8)):
             _require_device(ten, name)
@@ -125,7 +134,7 @@ class TraceFunction(torch.autograd.Function):
         if S > _lib.TL_MAX_SURFACES:
             raise RuntimeError(f"lens has {S} rows; this build supports at most {_lib.TL_MAX_SURFACES}")
         lib = _lib.lib()
-        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode)
+        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa, poly, kind_u8, n_index)
         nbytes = lib.tl_workspace_bytes(C.byref(prob))
         ws = _workspace(nbytes, dev)
         if want_rays:
@@ -133,12 +142,13 @@ class TraceFunction(torch.autograd.Function):
             bp = [torch.empty((1, F, W, P), dtype=torch.uint8, device=dev) for _ in range(2)]
         else:
             fp, bp = [None] * 4, [None] * 2
+        opd = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if want_opd else None
         moments = torch.empty((F, TL_NMOM), dtype=torch.float64, device=dev)
         with torch.cuda.device(dev), _Timed("fwd", dev):
             rc = lib.tl_trace_fwd(C.byref(prob), *[_lib.ptr(b) for b in fp], *[_lib.ptr(b) for b in bp],
-                                  None, _lib.ptr(moments), _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
+                                  _lib.ptr(opd), _lib.ptr(moments), _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
         _lib.check(rc, "tl_trace_fwd")
-        ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8)
+        ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8)
         ctx.allow_back, ctx.mode = allow_back, mode
         ctx.set_materialize_grads(False)
         if want_rays:
@@ -147,19 +157,22 @@ class TraceFunction(torch.autograd.Function):
         else:
             outs = [torch.empty(0, device=dev) for _ in range(4)]
             flags = [torch.empty(0, dtype=torch.bool, device=dev) for _ in range(2)]
-        ctx.mark_non_differentiable(*flags)
-        return (*outs, *flags, moments)
+        opd_out = opd.permute(0, 1, 3, 2) if want_opd else torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(*flags, opd_out)
+        return (*outs, *flags, moments, opd_out)
 
     @staticmethod
-    def backward(ctx, gx, gy, gcx, gcy, _gok, _gback, gmom):
-        x_e, y_e, z, cx, cy, c, t, mu, mask_u8 = ctx.saved_tensors
+    def backward(ctx, gx, gy, gcx, gcy, _gok, _gback, gmom, _gopd):
+        x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8 = ctx.saved_tensors
         dev = x_e.device
         F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
         S = c.numel()
+        n_in = 17
         if gx is None and gy is None and gcx is None and gcy is None and gmom is None:
-            return (None,) * 12
+            return (None,) * n_in
+        asph = kind_u8 is not None
         lib = _lib.lib()
-        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, ctx.allow_back, ctx.mode)
+        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, ctx.allow_back, ctx.mode, kappa, poly, kind_u8)
         ws = _workspace(lib.tl_workspace_bytes(C.byref(prob)), dev)
 
         def dense(g):
@@ -171,16 +184,17 @@ class TraceFunction(torch.autograd.Function):
         need_xin, need_yin = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gxin = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if need_xin else None
         gyin = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if need_yin else None
-        gpar = torch.empty(2 * S + W * S + 1 + 2 * F, dtype=torch.float64, device=dev)
-        g_c, g_t, g_mu, g_z, g_cx, g_cy = torch.split(gpar, [S, S, W * S, 1, F, F])
+        sizes = [S, S, W * S, 1, F, F] + ([S, 4 * S] if asph else [])
+        gpar = torch.empty(sum(sizes), dtype=torch.float64, device=dev)
+        parts = torch.split(gpar, sizes)
+        g_kappa, g_poly = (parts[6], parts[7]) if asph else (None, None)
         with torch.cuda.device(dev), _Timed("bwd", dev):
             rc = lib.tl_trace_bwd(C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd),
-                                  _lib.ptr(gmd), _lib.ptr(g_c), _lib.ptr(g_t), _lib.ptr(g_mu), _lib.ptr(g_z),
-                                  _lib.ptr(g_cx), _lib.ptr(g_cy), None, None, _lib.ptr(gxin), _lib.ptr(gyin),
-                                  _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
+                                  _lib.ptr(gmd), *[_lib.ptr(q) for q in parts[:6]], _lib.ptr(g_kappa), _lib.ptr(g_poly),
+                                  _lib.ptr(gxin), _lib.ptr(gyin), _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
         _lib.check(rc, "tl_trace_bwd")
-        f32 = gpar.to(torch.float32)
-        g_c, g_t, g_mu, g_z, g_cx, g_cy = torch.split(f32, [S, S, W * S, 1, F, F])
+        parts = torch.split(gpar.to(torch.float32), sizes)
+        g_c, g_t, g_mu, g_z, g_cx, g_cy = parts[:6]
         if cx.numel() == 1:
             g_cx = g_cx.sum(dim=0, keepdim=True)
         if cy.numel() == 1:
@@ -189,7 +203,8 @@ class TraceFunction(torch.autograd.Function):
                 gyin.permute(0, 1, 3, 2) if need_yin else None,
                 g_z.reshape(z.shape), g_cx.reshape(cx.shape), g_cy.reshape(cy.shape),
                 g_c.reshape(c.shape), g_t.reshape(t.shape), g_mu.reshape(mu.shape),
-                None, None, None, None)
+                parts[6].reshape(kappa.shape) if asph else None, parts[7].reshape(poly.shape) if asph else None,
+                None, None, None, None, None, None, None)
 
 
 class SpotMomentsFunction(torch.autograd.Function):

@@ -32,13 +32,27 @@ def _flat(scale, radii, thick):
     return c, t
 
 
-def double_gauss(device="cuda", requires_grad=True, dtype=torch.float32):
-    """Returns (lens, specs, leaves) for the 11-row all-spherical double Gauss.
+# the 2-asphere variant (BASELINE configs[2]): mild conic + 4th/6th-order terms on the rear surface of
+# the first element (row 1) and on the last surface (row 10); values chosen so that every ray of the
+# f/3, 14-degree fan still passes and the Newton iteration has real work to do (sag departure ~1 um)
+_DG_ASPH = {1: (-0.6, (2.0e-6, -4.0e-8, 0.0, 0.0)), 10: (0.4, (-3.0e-6, 5.0e-8, 0.0, 0.0))}
+
+
+def double_gauss(device="cuda", requires_grad=True, dtype=torch.float32, aspheres=False):
+    """Returns (lens, specs, leaves) for the 11-row double Gauss; `aspheres=True` makes rows 1 and 10
+    aspheric (leaves then also hold kappa [11] and poly [11,4]).
     epd = EFL/3, half field 14 degrees (the form's native aperture and field)."""
     s = TARGET_EFL / _DG_EFL
     c, t = _flat(s, _DG_R, _DG_T)
+    asph = None
+    if aspheres:
+        kap = [0.0] * len(c)
+        pol = [[0.0] * 4 for _ in c]
+        for row, (k, a) in _DG_ASPH.items():
+            kap[row], pol[row] = k, list(a)
+        asph = (kap, pol)
     return _build(_DG_SEQ, 5, c, t, _DG_GLASS, epd=TARGET_EFL / 3.0, hfov_deg=14.0, device=device,
-                  requires_grad=requires_grad, dtype=dtype)
+                  requires_grad=requires_grad, dtype=dtype, asph=asph)
 
 
 def zoom20(device="cuda", requires_grad=True, dtype=torch.float32):
@@ -61,11 +75,13 @@ def zoom20(device="cuda", requires_grad=True, dtype=torch.float32):
                   requires_grad=requires_grad, dtype=dtype)
 
 
-def _build(seq, stop, c, t, glass, epd, hfov_deg, device, requires_grad, dtype):
+def _build(seq, stop, c, t, glass, epd, hfov_deg, device, requires_grad, dtype, asph=None):
     st = lm.Structure(stop_idx=np.array([stop]), sequence=np.array([seq]), default_device=device)
     mk = lambda v: torch.tensor(v, dtype=dtype, device=device, requires_grad=requires_grad)  # noqa: E731
     leaves = dict(c=mk(c), t=mk(t), nd=mk([g[0] for g in glass]), v=mk([g[1] for g in glass]))
-    lens = lm.Lens(st, leaves["c"], leaves["t"], leaves["nd"], leaves["v"])
+    if asph is not None:
+        leaves.update(kappa=mk(asph[0]), poly=mk(asph[1]))
+    lens = lm.Lens(st, leaves["c"], leaves["t"], leaves["nd"], leaves["v"], leaves.get("kappa"), leaves.get("poly"))
     specs = lm.Specs(st, torch.tensor([epd], dtype=dtype, device=device),
                      torch.tensor([np.deg2rad(hfov_deg)], dtype=dtype, device=device))
     return lens, specs, leaves

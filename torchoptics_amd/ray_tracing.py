@@ -83,16 +83,22 @@ def _as_f32(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_rays=True, mode=None,
-               want_rays=True):
-    """Trace rays from the entrance pupil to the image plane through S spherical rows.
+               want_rays=True, kappa=None, poly=None, surf_kind=None, n_index=None, want_opd=False):
+    """Trace rays from the entrance pupil to the image plane through S surface rows.
 
     Same contract as the reference (ray_tracing_lite.py:594-675): inputs broadcast to
     [1, F, P, W]; returns (x, y, cx, cy, ray_ok, ray_backward).  Differentiable w.r.t.
     x, y, z, cx, cy, c, t, mu through a hand-written backward kernel.
 
-    Extras (not in the reference): `mode` 'strict'|'fast' (default ops.get_default_mode());
-    the returned `y` carries the fused spot moments so `compute_rms2d(x, y, ray_ok)` costs no
-    second pass over the rays.
+    Extras (not in the reference):
+      mode        'strict' | 'fast' arithmetic (default ops.get_default_mode());
+      kappa, poly aspheric rows: conic constants [S] and even polynomial terms [S,4] (a4..a10);
+                  `surf_kind` [S] (bool/int) marks the rows traced by Newton iteration -- default: the
+                  rows where kappa or poly is non-zero.  Differentiable w.r.t. kappa and poly too;
+      n_index, want_opd   refractive indices [1,1,1,W,S+1] (entry 0 = object space) and a seventh
+                  return value: the optical path length per ray (forward only, no gradient);
+      the returned `y` carries the fused spot moments so `compute_rms2d(x, y, ray_ok)` costs no
+      second pass over the rays.
     """
     if aggregate:
         raise NotImplementedError("aggregate=True (per-surface penalty stacks) is not built yet; "
@@ -117,14 +123,27 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
         raise ValueError("cx, cy must be per-field [1,F,1,1] or a single value")
     mu2 = mu.reshape(mu.shape[3], S).expand(W, S).contiguous()
     mask_u8 = mask.reshape(-1).to(torch.uint8).contiguous()
+    kap = pol = kind_u8 = None
+    if kappa is not None or poly is not None:
+        kap = _as_f32(kappa, 'kappa').reshape(S).contiguous() if kappa is not None else torch.zeros(S, device=c.device)
+        pol = (_as_f32(poly, 'poly').reshape(S, 4).contiguous() if poly is not None
+               else torch.zeros(S, 4, device=c.device))
+        if surf_kind is None:
+            surf_kind = (kap.detach() != 0) | (pol.detach() != 0).any(dim=1)
+        kind_u8 = torch.as_tensor(surf_kind, device=c.device).reshape(S).to(torch.uint8).contiguous()
+    nidx = None
+    if want_opd:
+        if n_index is None:
+            raise ValueError("want_opd=True needs n_index [1,1,1,W,S+1]")
+        nidx = _as_f32(n_index, 'n_index').reshape(-1, S + 1).expand(W, S + 1).contiguous()
     out = ops.TraceFunction.apply(x_e, y_e, z.reshape(1).contiguous(), cxv, cyv, c.reshape(S).contiguous(),
-                                  t.reshape(S).contiguous(), mu2, mask_u8, bool(allow_backward_rays),
-                                  mode or ops.get_default_mode(), want_rays)
-    xo, yo, cxo, cyo, ok, back, moments = out
+                                  t.reshape(S).contiguous(), mu2, kap, pol, mask_u8, kind_u8, nidx,
+                                  bool(allow_backward_rays), mode or ops.get_default_mode(), want_rays, bool(want_opd))
+    xo, yo, cxo, cyo, ok, back, moments, opd = out
     if want_rays:
         # remember which moments belong to these rays (checked by identity + version in compute_rms2d)
         yo._tl_spot = (moments, ok, yo._version, P * W)
-        return xo, yo, cxo, cyo, ok, back
+        return (xo, yo, cxo, cyo, ok, back, opd) if want_opd else (xo, yo, cxo, cyo, ok, back)
     return moments
 
 
@@ -211,16 +230,29 @@ class RayTracer:
         fields = torch.tensor(self.rel_fields, dtype=torch.float32).to(dev)
         cy = torch.sin((specs.hfov[:, None] * fields[None, :])[..., None, None])
         cx = torch.zeros(1, device=dev).reshape(1, 1, 1, 1)
-        return dict(
+        out = dict(
             x=scale_to_epd(xp_rel.to(dev), specs.epd), y=scale_to_epd(yp_rel.to(dev), specs.epd), z=z, cx=cx, cy=cy,
             c=lens.c.reshape(lens.c.shape[0], 1, 1, 1, -1), t=lens.t.reshape(lens.t.shape[0], 1, 1, 1, -1),
             mu=n[..., :-1] / n[..., 1:],
             mask=lens.structure.mask_torch.reshape(lens.c.shape[0], 1, 1, 1, -1))
+        if getattr(lens, "kappa", None) is not None:        # aspheric extension of Lens (not in the reference)
+            out.update(kappa=lens.kappa, poly=lens.poly, n_index=n)
+        return out
 
-    def trace_rays(self, specs, lens, use_vig=True, aggregate=False, xy=None, up_to_stop=False):
+    def trace_rays(self, specs, lens, use_vig=True, aggregate=False, xy=None, up_to_stop=False, want_opd=False):
         a = self.assemble(specs, lens, xy=xy, up_to_stop=up_to_stop, use_vig=use_vig)
+        extra = {}
+        if "kappa" in a:
+            extra.update(kappa=a["kappa"], poly=a["poly"])
+        if want_opd:
+            n = a.get("n_index")
+            if n is None:
+                n = lens.get_refractive_indices(self.wavelengths)
+                n = torch.cat((torch.ones_like(n[:, :1, :]), n), dim=1).transpose(1, 2)
+                n = n.reshape(n.shape[0], 1, 1, n.shape[1], -1)
+            extra.update(n_index=n, want_opd=True)
         return trace_skew(a['x'], a['y'], a['z'], a['cx'], a['cy'], a['c'], a['t'], a['mu'], a['mask'],
-                          aggregate, self.allow_backward_rays, mode=self.arith)
+                          aggregate, self.allow_backward_rays, mode=self.arith, **extra)
 
     # -- ray aiming (ray_tracing_lite.py:129-208) ---------------------------------------------
     def ray_aiming(self, specs, lens, use_vig):
