@@ -19,6 +19,8 @@ Workloads:
         (0.707), W=1 ('d'), circular pupil grid 4096 x 4096 = 2^24 rays PER GPU (weak scaling; at
         N=8 this is cfg4's 2^27 rays).  This is the config BASELINE.json's metric ("M rays/s
         through 10-surface lens; fwd+bwd") is quoted on.
+  cfg3a: the same double Gauss with 2 aspheric rows (conic + a4, a6; Newton intersection) -- BASELINE
+        configs[2] as written; an extension beyond the reference (parity unpinned by it).
   cfg2: Cooke triplet (7 rows), 1024 x 1024 pupil, 3 fields, W=1.
   cfg5: 20-row synthetic zoom, 5 fields x 3 wavelengths, 1024 x 1024 pupil.
 """
@@ -35,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+LEAF_NAMES = ("z", "cy", "c", "t", "mu", "kappa", "poly")   # differentiable arguments of trace_skew
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector (packed FMA)
 
@@ -44,13 +47,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg3a", "cfg2", "cfg5"])
     ap.add_argument("--mode", default=os.environ.get("TORCHOPTICS_AMD_MODE", "strict"), choices=["strict", "fast"])
     ap.add_argument("--log2-pupil", type=int, default=None, help="override log2 of pupil points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the secondary measurement of the other arithmetic mode")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra workloads reported next to the main one")
     ap.add_argument("--cpu-log2-rays", type=int, default=20, help="log2 of the CPU-baseline sample (rays)")
     return ap.parse_args()
 
@@ -59,8 +63,8 @@ def workload(name, device, world, rank, log2_pupil):
     """Returns dict(lens args as leaves, pupil slice, meta)."""
     import torchoptics_amd as ta
     from torchoptics_amd import prescriptions as P, ray_tracing as rt
-    if name == "cfg3":
-        lens, specs, leaves = P.double_gauss(device)
+    if name in ("cfg3", "cfg3a"):
+        lens, specs, leaves = P.double_gauss(device, aspheres=(name == "cfg3a"))
         fields, wl, lp = (0.707,), ("d",), 24
     elif name == "cfg2":
         import yaml_free_lenses as L
@@ -78,9 +82,10 @@ def workload(name, device, world, rank, log2_pupil):
     xy = rt.circle_index_range(n_r, n_theta_total, rank * p_local, (rank + 1) * p_local, device)
     with torch.no_grad():
         a = tr.assemble(specs, lens, xy=xy)
-    args = {k: v.detach().clone() for k, v in a.items()}
-    for k in ("z", "cy", "c", "t", "mu"):
-        args[k].requires_grad_(True)
+    args = {k: v.detach().clone() for k, v in a.items() if k != "n_index"}
+    for k in LEAF_NAMES:
+        if k in args:
+            args[k].requires_grad_(True)
     meta = dict(F=len(fields), W=len(wl), S=lens.c.shape[1], P_local=p_local, P_total=p_local * world,
                 lens=name, fields=list(map(float, fields)), wavelengths=list(wl))
     return args, meta, (tr, specs, lens, leaves, xy)
@@ -138,14 +143,15 @@ def main():
     ops.set_default_mode(a.mode)
 
     args, meta, extra = workload(a.workload, device, world, rank, a.log2_pupil)
-    leaves = [args[k] for k in ("z", "cy", "c", "t", "mu")]
+    leaves = [args[k] for k in LEAF_NAMES if k in args]
+    asph = {k: args[k] for k in ("kappa", "poly") if k in args}
     n_per_field_total = meta["P_total"] * meta["W"]
 
     def step():
         for p in leaves:
             p.grad = None
         x, y, cx, cy, ok, back = ta.trace_skew(args["x"], args["y"], args["z"], args["cx"], args["cy"], args["c"],
-                                               args["t"], args["mu"], args["mask"])
+                                               args["t"], args["mu"], args["mask"], **asph)
         rms = ta.compute_rms2d(x, y, ok, group=group, n_per_field=n_per_field_total)
         rms.backward()
         if group is not None:
@@ -187,7 +193,7 @@ def main():
     # ---- roofline of the dominant kernel (trace_bwd_kernel), per launch, from live event timing
     fw = meta["F"] * meta["W"]
     b_fwd, b_bwd = 18.0 + 8.0 / fw, 8.0 / fw      # algorithmic bytes per ray (DESIGN.md "bytes per unit")
-    f_fwd, f_bwd = flops_per_ray(meta["S"])
+    f_fwd, f_bwd = flops_per_ray(meta["S"])     # counted for spherical rows; aspheric rows cost more (not counted)
     kernels = {}
     for key, bpr, fpr in (("fwd", b_fwd, f_fwd), ("bwd", b_bwd, f_bwd)):
         ms = kern_ms.get(key)
@@ -218,6 +224,22 @@ def main():
                      fwd_kernel_ms=okm.get("fwd"), bwd_kernel_ms=okm.get("bwd"), rms=float(orms.item()))
         ops.set_default_mode(a.mode)
 
+    # secondary workloads, same protocol (W warm-up + K timed steps), reported under "also"
+    also = {}
+    if not a.no_also and a.workload == "cfg3" and a.log2_pupil is None:
+        main_state = (args, meta, leaves, asph, n_per_field_total)
+        for wname in ("cfg3a", "cfg2"):
+            args, meta2, _ = workload(wname, device, world, rank, None)
+            leaves = [args[k] for k in LEAF_NAMES if k in args]
+            asph = {k: args[k] for k in ("kappa", "poly") if k in args}
+            n_per_field_total = meta2["P_total"] * meta2["W"]
+            adt, akm, arms = timed(a.mode)
+            nr = meta2["F"] * meta2["W"] * meta2["P_local"] * world
+            also[wname] = dict(value=nr * a.steps / adt / 1e6, unit="M rays/s", ms_per_step=adt / a.steps * 1e3,
+                               fwd_kernel_ms=akm.get("fwd"), bwd_kernel_ms=akm.get("bwd"), rays=nr, rows=meta2["S"],
+                               F=meta2["F"], W=meta2["W"], rms=float(arms.item()), arith_mode=a.mode)
+        args, meta, leaves, asph, n_per_field_total = main_state
+
     cpu_baseline, grad_check = None, None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu_baseline, grad_check = cpu_leg(args, meta, a.cpu_log2_rays, a.mode)
@@ -236,6 +258,7 @@ def main():
             "step_hbm_GBs": step_bytes / (dt / a.steps) / 1e9,
             "grad_rel_err_vs_pytorch_autograd": grad_check,
             "other_mode": other,
+            "also": also,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
@@ -261,8 +284,10 @@ def cpu_leg(args, meta, log2_rays, mode):
     p = max(1, min(meta["P_local"], (1 << log2_rays) // fw))
     cpu = {k: v.detach().cpu() for k, v in args.items()}
     cpu["x"], cpu["y"] = cpu["x"][:, :, :p].contiguous(), cpu["y"][:, :, :p].contiguous()
-    names = ("z", "cy", "c", "t", "mu")
+    names = tuple(k for k in LEAF_NAMES if k in cpu)
     leaves = [cpu[k].requires_grad_(True) for k in names]
+    is_asph = "kappa" in cpu
+    kind = ((cpu["kappa"].reshape(-1) != 0) | (cpu["poly"].reshape(-1, 4) != 0).any(dim=1)).int().tolist() if is_asph else None
 
     def one(dt=None, ieee=False):
         src = cpu if dt is None else {k: (v.to(dt) if v.is_floating_point() else v) for k, v in cpu.items()}
@@ -271,8 +296,13 @@ def cpu_leg(args, meta, log2_rays, mode):
             src.update(dict(zip(names, lv)))
         for q in lv:
             q.grad = None
-        x, y, cx, cy, ok, back = orc.trace_skew(src["x"], src["y"], src["z"], src["cx"], src["cy"], src["c"], src["t"],
-                                                src["mu"], src["mask"], ieee_sqrt=ieee)
+        if is_asph:
+            x, y, cx, cy, ok, back, _ = orc.trace_skew_general(
+                src["x"], src["y"], src["z"], src["cx"], src["cy"], src["c"], src["t"], src["mu"], src["mask"],
+                src["kappa"].reshape(-1), src["poly"].reshape(-1, 4), kind, ieee_sqrt=ieee)
+        else:
+            x, y, cx, cy, ok, back = orc.trace_skew(src["x"], src["y"], src["z"], src["cx"], src["cy"], src["c"],
+                                                    src["t"], src["mu"], src["mask"], ieee_sqrt=ieee)
         orc.compute_rms2d(x, y, ok).backward()
         return [q.grad.clone() for q in lv]
     t0 = time.perf_counter()
@@ -293,7 +323,8 @@ def cpu_leg(args, meta, log2_rays, mode):
     ga = dict(args)
     ga.update(dict(zip(names, gl)))
     x, y, cx, cy, ok, back = ta.trace_skew(args["x"][:, :, :p].contiguous(), args["y"][:, :, :p].contiguous(), ga["z"],
-                                           ga["cx"], ga["cy"], ga["c"], ga["t"], ga["mu"], ga["mask"], mode=mode)
+                                           ga["cx"], ga["cy"], ga["c"], ga["t"], ga["mu"], ga["mask"], mode=mode,
+                                           **{k: ga[k] for k in ("kappa", "poly") if k in ga})
     ta.compute_rms2d(x, y, ok).backward()
 
     def rel(a, b):
@@ -303,7 +334,7 @@ def cpu_leg(args, meta, log2_rays, mode):
         gc[k] = dict(vs_fp32_autograd_ieee_sqrt=rel(q.grad.cpu(), r32i), vs_fp32_autograd_mkl_sqrt=rel(q.grad.cpu(), r32),
                      vs_fp64_autograd=rel(q.grad.cpu(), r64), fp32_autograd_mkl_vs_ieee=rel(r32, r32i),
                      fp32_autograd_mkl_vs_fp64=rel(r32, r64))
-    lens_groups = ("c", "t", "mu")
+    lens_groups = tuple(k for k in ("c", "t", "mu", "kappa", "poly") if k in gc)
     grad_check = dict(sample_rays=p * fw, arith_mode=mode, per_group=gc,
                       max_vs_fp32_autograd=max(gc[k]["vs_fp32_autograd_ieee_sqrt"] for k in lens_groups),
                       max_vs_fp32_autograd_mkl_sqrt=max(gc[k]["vs_fp32_autograd_mkl_sqrt"] for k in lens_groups),
