@@ -26,9 +26,9 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 4
+#define TL_ABI_VERSION 5
 #define TL_MAX_SURFACES 32       /* rows per lens the backward kernels are built for */
-#define TL_NMOM 8                /* spot moments per field, see tl_trace_fwd */
+#define TL_NMOM 10               /* per-field sums, see tl_trace_fwd */
 #define TL_MAX_POLY 4            /* even aspheric terms a4,a6,a8,a10 */
 
 enum {
@@ -52,7 +52,7 @@ typedef struct tl_problem {
     int32_t device;              /* HIP device ordinal the pointers live on */
     int32_t mode;                /* TL_MODE_* */
     int32_t allow_backward;      /* allow_backward_rays (ray_tracing_lite.py:629) */
-    int32_t reserved0;
+    int32_t aggregate;           /* aggregate=True of trace_skew (:641-657): evaluate the penalty-term quantities */
     /* entrance-pupil ray coordinates; element strides (floats) over (f, p, w), 0 = broadcast.
        Reference shapes [1|B, 1|F, P, 1|W] (ray_tracing_lite.py:112-113). */
     const float *x_in, *y_in;
@@ -94,13 +94,17 @@ size_t tl_workspace_bytes(const tl_problem *p);
  *               forward only: no gradient flows through it)
  *   moments   : [F,TL_NMOM] double (nullable), per field over (w,p):
  *               0 sum y | 1 sum ok*y | 2 sum ok*y^2 | 3 sum ok | 4 sum x | 5 sum ok*x |
- *               6 sum ok*x^2 | 7 sum back
- *               -- the sufficient statistics of compute_rms2d (ray_tracing_lite.py:678-702),
- *               reduced in a fixed order (bitwise reproducible).
+ *               6 sum ok*x^2 | 7 sum back | 8 sum q (p->aggregate only) | 9 reserved
+ *               -- 0..3 are the sufficient statistics of compute_rms2d (ray_tracing_lite.py:678-702);
+ *               q = per-ray sum over the surfaces of theta_norm + theta_prime_norm + z_RELU
+ *               (ray_tracing_lite.py:641-657), NaN -> 0, i.e. sumQ * n_sequence of
+ *               optics_simulator_lite.py:441-448.  All reduced in a fixed order (bitwise reproducible).
+ *   stacks    : [3][S][F,W,P] float (nullable, p->aggregate only): the per-surface stacks
+ *               z_RELU | theta_norm | theta_prime_norm that trace_skew(aggregate=True) returns.
  */
 int tl_trace_fwd(const tl_problem *p,
                  float *x, float *y, float *cx, float *cy, uint8_t *ok, uint8_t *back,
-                 float *opd, double *moments,
+                 float *opd, float *stacks, double *moments,
                  void *workspace, size_t workspace_bytes, void *stream);
 
 /*
@@ -109,7 +113,8 @@ int tl_trace_fwd(const tl_problem *p,
  * reverse.
  *   gx,gy,gcx,gcy : [F,W,P] upstream gradients of the per-ray outputs (each nullable)
  *   g_moments     : [F,TL_NMOM] double upstream gradient of `moments` (nullable); the per-ray
- *                   seed  gM0 + ok*(gM1 + 2*y*gM2)  (and the x analogue) is formed in-kernel
+ *                   seed  gM0 + ok*(gM1 + 2*y*gM2)  (and the x analogue) is formed in-kernel;
+ *                   entry 8 seeds the penalty term when p->aggregate
  *   g_c,g_t [S], g_mu [W,S], g_z [1], g_cx,g_cy [F] : double, OVERWRITTEN (not accumulated)
  *   g_kappa [S], g_poly [S,TL_MAX_POLY] : double, nullable (aspheric extension)
  *   g_x_in,g_y_in : [F,W,P] float per-ray input gradients (nullable; used by ray aiming,

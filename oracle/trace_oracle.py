@@ -189,14 +189,20 @@ def _trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays)
             full = (*r.x.shape[:3], n_wave)
             z_relu = torch.where(r.z <= 0, torch.zeros_like(r.z), r.z)
             lo, hi = -1.0 + ACOS_EPS, 1.0 - ACOS_EPS
-            th_i = torch.acos(torch.clamp(torch.sqrt(cos2_i), min=lo, max=hi)) / (1 / 2 * math.pi)
-            th_t = torch.acos(torch.clamp(torch.sqrt(cos2_t), min=lo, max=hi)) / (1 / 2 * math.pi)
-            # the reference indexes theta[~ray_ok] in place, which only works when the
-            # shapes already agree; broadcast first, same values.
+            # The reference takes sqrt(cos2) of EVERY ray and overwrites theta of the dead ones with 1
+            # afterwards (in place, which only works when shapes already agree: SURVEY Appendix B5).
+            # For a missed ray cos2 < 0, sqrt is NaN, and although the forward value is overwritten the
+            # backward multiplies a zero gradient by NaN: the reference's penalty gradient is NaN as soon
+            # as one ray misses.  Same forward values here, but the sqrt argument of dead rays is
+            # replaced by 1 first, so masked rays contribute exactly zero gradient.
             ok_b = torch.broadcast_to(r.ok, full)
-            one = torch.ones((), dtype=th_i.dtype, device=th_i.device)
-            th_i = torch.where(ok_b, torch.broadcast_to(th_i, full), one)
-            th_t = torch.where(ok_b, torch.broadcast_to(th_t, full), one)
+            one = torch.ones((), dtype=r.x.dtype, device=r.x.device)
+            safe_i = torch.where(ok_b, torch.broadcast_to(cos2_i, full), one)
+            safe_t = torch.where(ok_b, torch.broadcast_to(cos2_t, full), one)
+            th_i = torch.acos(torch.clamp(torch.sqrt(safe_i), min=lo, max=hi)) / (1 / 2 * math.pi)
+            th_t = torch.acos(torch.clamp(torch.sqrt(safe_t), min=lo, max=hi)) / (1 / 2 * math.pi)
+            th_i = torch.where(ok_b, th_i, one)
+            th_t = torch.where(ok_b, th_t, one)
             stacks['z_RELU'].append(torch.broadcast_to(z_relu, full))
             stacks['theta_norm'].append(th_i)
             stacks['theta_prime_norm'].append(th_t)

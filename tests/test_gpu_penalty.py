@@ -1,0 +1,111 @@
+"""
+GPU tests of the penalty term (trace_skew(aggregate=True)): the per-surface
+stacks, the fused sum and its gradient, against fixture G7 (the reference's own
+RaytracedOptics.do_ray_tracing: loss_dict, stacks, leaf gradients) and against the oracle.
+
+Tolerances: z_RELU 1e-5 mm; theta stacks 3e-6 (device acosf vs the CPU's, near cos = 1 the acos
+amplifies 1 ulp of cos to ~3e-4 of theta in RELATIVE terms, so the bound is absolute on theta/(pi/2));
+penalty sum 2e-6 relative.  Gradients: d theta/d cos^2 = -1/(2 h u sqrt(1-u^2)) reaches ~2000 towards
+normal incidence while d cos^2/d(inputs) vanishes there by cancellation, so rays within ~0.002 rad of a
+surface normal carry percent-level fp32 noise in ANY fp32 evaluation (the oracle's own fp32 autograd is
+2e-5..1e-3 from its fp64).  Bounds vs the fp64 oracle: lens parameters c, t, mu 1e-4 + 2x the oracle's
+fp32 noise; launch conditions z, cy (cancellation-heavy sums) 2e-3 + 2x.  Measured on the 9k-ray cases:
+1e-6..5e-6 from the oracle's fp32 (IEEE sqrt) autograd in every group.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+IN = ("in_x", "in_y", "in_z", "in_cx", "in_cy", "in_c", "in_t", "in_mu")
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import torchoptics_amd
+    from torchoptics_amd import _lib
+    _lib.lib()
+    return torchoptics_amd
+
+
+def test_stacks_and_loss_dict_match_reference_fixture(ta):
+    from torchoptics_amd import ray_tracing as rt
+    g = load_golden("G7_harness_cooke")
+    ins = [torch.from_numpy(g[n]).to(DEV) for n in IN]
+    out = ta.trace_skew(*ins, torch.from_numpy(g["in_mask"]).to(DEV), True, True)
+    assert len(out) == 7
+    stacks = out[6]
+    assert set(stacks) == {"z_RELU", "theta_norm", "theta_prime_norm"} and len(stacks["z_RELU"]) == 7
+    for key, tol in (("z_RELU", 1e-5), ("theta_norm", 3e-6), ("theta_prime_norm", 3e-6)):
+        got = torch.stack(stacks[key], 0).cpu().numpy()
+        assert got.shape == g["stack_" + key].shape
+        assert np.abs(got - g["stack_" + key]).max() <= tol, key
+    n_seq = int(g["n_sequence"])
+    ld = rt.unsupervised_loss(out, n_seq, 0.2)
+    assert abs(ld["penalty"].item() - float(g["penalty"])) <= 2e-6 * float(g["penalty"])
+    assert abs(ld["rms"].item() - float(g["rms"])) <= 5e-6 * float(g["rms"])
+    assert abs(ld["loss_unsup"].item() - float(g["loss_unsup"])) <= 2e-6 * float(g["loss_unsup"])
+    # the value-only path (plain dict of tensors) gives the same number
+    plain = {k: v for k, v in stacks.items()}
+    assert abs(rt.penalty_sum(plain, n_seq).item() - ld["penalty"].item()) <= 1e-5 * ld["penalty"].item()
+
+
+@pytest.mark.parametrize("case", ["G7_harness_cooke", "G5_cooke_failures", "G10_cooke_noback"])
+def test_penalty_gradient_matches_oracle(ta, case):
+    """d(sumQ)/d(c, t, mu, z, cy): includes rays that die part-way (they keep gradient through the
+    surfaces they passed alive) and parked rays."""
+    from oracle import trace_oracle as orc
+    from torchoptics_amd import ray_tracing as rt
+    g = load_golden(case)
+    mask = torch.from_numpy(g["in_mask"])
+    allow = bool(g.get("allow_backward_rays", True))
+    n_seq = 7
+    res = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        ins = [torch.from_numpy(g[n]).to(dt) for n in IN]
+        lv = [ins[i].clone().requires_grad_(True) for i in (2, 4, 5, 6, 7)]
+        o = orc.trace_skew(ins[0], ins[1], lv[0], ins[3], lv[1], lv[2], lv[3], lv[4], mask, True, allow,
+                           ieee_sqrt=(dt == torch.float32))
+        pen = orc.penalty_from_stacks(o[6], n_seq)
+        pen.backward()
+        res[tag] = (pen.item(), [q.grad for q in lv])
+    ins = [torch.from_numpy(g[n]).to(DEV) for n in IN]
+    lv = [ins[i].clone().requires_grad_(True) for i in (2, 4, 5, 6, 7)]
+    o = ta.trace_skew(ins[0], ins[1], lv[0], ins[3], lv[1], lv[2], lv[3], lv[4], mask.to(DEV), True, allow)
+    pen = rt.penalty_sum(o[6], n_seq)
+    pen.backward()
+    # acos near cos = 1 makes the fp32 sum itself ~7e-6 off its fp64 value (the reference's fp32 too)
+    assert abs(pen.item() - res["f64"][0]) <= 3e-6 * abs(res["f64"][0]) + 2 * abs(res["f32"][0] - res["f64"][0])
+    for n, q, g32, g64 in zip(("z", "cy", "c", "t", "mu"), lv, *[res[k][1] for k in ("f32", "f64")]):
+        e64, noise = rel_l2(q.grad.cpu().numpy(), g64.numpy()), rel_l2(g32.numpy(), g64.numpy())
+        print(f"{case} penalty d/d{n}: vs fp64 {e64:.2e} (oracle fp32 itself {noise:.2e})")
+        assert e64 <= (1e-4 if n in ("c", "t", "mu") else 2e-3) + 2 * noise, f"{case} d/d{n}: {e64:.2e}"
+
+
+def test_full_chain_harness_equivalent_matches_reference(ta):
+    """The reference's RaytracedOptics.do_ray_tracing case of fixture G7 through this package:
+    8x8 circular pupil, 3 fields, (459,520,640) nm, one ray-aiming iteration, aggregate=True."""
+    import yaml_free_lenses as L
+    from torchoptics_amd import ray_tracing as rt
+    g = load_golden("G7_harness_cooke")
+    lens, specs, leaves = L.build("cooke", DEV, epd=8.578)
+    tr = ta.RayTracer(mode="circular", n_rays=(8, 8), rel_fields=list(np.linspace(0, 1, 3)), wavelengths=[459., 520., 640.],
+                      n_ray_aiming_iter=1, default_device=DEV)
+    out = tr.trace_rays(specs, lens, aggregate=True)
+    ld = rt.unsupervised_loss(out, 7, 0.2)
+    for k in ("loss_unsup", "rms", "penalty"):
+        assert abs(ld[k].item() - float(g[k])) <= 2e-5 * abs(float(g[k])), (k, ld[k].item(), float(g[k]))
+    grads = torch.autograd.grad(ld["loss_unsup"], [leaves[k] for k in ("c", "t", "nd")])
+    for k, got in zip(("c", "t", "nd"), grads):
+        err = rel_l2(got.cpu().numpy(), g["g_loss_unsup_" + k])
+        assert err <= 3e-4, f"d loss_unsup / d{k}: {err:.2e}"     # fp32 autograd through acos near 1 is itself ~1e-4 noisy
+
+
+def test_aggregate_with_aspheres_is_refused(ta):
+    g = load_golden("G2_cooke_16x16")
+    ins = [torch.from_numpy(g[n]).to(DEV) for n in IN]
+    with pytest.raises(NotImplementedError):
+        ta.trace_skew(*ins, torch.from_numpy(g["in_mask"]).to(DEV), True, True, kappa=torch.full((7,), -0.5, device=DEV))

@@ -43,8 +43,8 @@ def main():
                         mu2, mask, True, a.mode)
     outs = [torch.empty((1, F, W, P), dtype=torch.float32, device=dev) for _ in range(4)]
     flags = [torch.empty((1, F, W, P), dtype=torch.uint8, device=dev) for _ in range(2)]
-    mom = torch.empty((F, 8), dtype=torch.float64, device=dev)
-    gmom = torch.randn((F, 8), dtype=torch.float64, device=dev) * 1e-3
+    mom = torch.empty((F, _lib.TL_NMOM), dtype=torch.float64, device=dev)
+    gmom = torch.randn((F, _lib.TL_NMOM), dtype=torch.float64, device=dev) * 1e-3
     gpar = torch.empty(2 * S + W * S + 1 + 2 * F, dtype=torch.float64, device=dev)
     g_c, g_t, g_mu, g_z, g_cx, g_cy = torch.split(gpar, [S, S, W * S, 1, F, F])
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
@@ -60,7 +60,7 @@ def main():
     P_ = _lib.ptr
 
     def fwd(dll):
-        rc = dll.tl_trace_fwd(C.byref(prob), *[P_(o) for o in outs], *[P_(f) for f in flags], None, P_(mom), P_(ws),
+        rc = dll.tl_trace_fwd(C.byref(prob), *[P_(o) for o in outs], *[P_(f) for f in flags], None, None, P_(mom), P_(ws),
                               ws.numel(), st)
         assert rc == 0, dll.tl_last_error()
 

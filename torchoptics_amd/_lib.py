@@ -11,8 +11,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtltrace.so")
 
-TL_ABI_VERSION = 4
-TL_NMOM = 8
+TL_ABI_VERSION = 5
+TL_NMOM = 10
 TL_MAX_SURFACES = 32
 TL_MAX_POLY = 4
 MODE_STRICT, MODE_FAST = 0, 1
@@ -21,7 +21,7 @@ MODE_STRICT, MODE_FAST = 0, 1
 class tl_problem(C.Structure):
     _fields_ = [
         ("F", C.c_int32), ("P", C.c_int32), ("W", C.c_int32), ("S", C.c_int32),
-        ("device", C.c_int32), ("mode", C.c_int32), ("allow_backward", C.c_int32), ("reserved0", C.c_int32),
+        ("device", C.c_int32), ("mode", C.c_int32), ("allow_backward", C.c_int32), ("aggregate", C.c_int32),
         ("x_in", C.c_void_p), ("y_in", C.c_void_p),
         ("xs_f", C.c_int64), ("xs_p", C.c_int64), ("xs_w", C.c_int64),
         ("ys_f", C.c_int64), ("ys_p", C.c_int64), ("ys_w", C.c_int64),
@@ -41,7 +41,7 @@ _SIGNATURES = {
     "tl_last_error": (C.c_char_p, []),
     "tl_problem_size": (C.c_size_t, []),
     "tl_workspace_bytes": (C.c_size_t, [C.POINTER(tl_problem)]),
-    "tl_trace_fwd": (C.c_int, [C.POINTER(tl_problem)] + [_VP] * 8 + [_VP, C.c_size_t, _VP]),
+    "tl_trace_fwd": (C.c_int, [C.POINTER(tl_problem)] + [_VP] * 9 + [_VP, C.c_size_t, _VP]),
     "tl_trace_bwd": (C.c_int, [C.POINTER(tl_problem)] + [_VP] * 15 + [_VP, C.c_size_t, _VP]),
     "tl_spot_moments": (C.c_int, [C.c_int32] * 4 + [_VP] * 3 + [C.c_int64] * 3 + [_VP, _VP, C.c_size_t, _VP]),
     "tl_spot_seed": (C.c_int, [C.c_int32] * 4 + [_VP] * 3 + [C.c_int64] * 3 + [_VP] * 4),

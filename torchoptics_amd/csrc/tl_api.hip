@@ -71,6 +71,8 @@ int check_problem(const tl_problem *p)
     if ((p->cx_stride | 1) != 1 || (p->cy_stride | 1) != 1) return fail(TL_EINVAL, "cx/cy stride must be 0 or 1");
     if ((p->surf_kind != nullptr) != (p->kappa != nullptr) || (p->surf_kind != nullptr) != (p->poly != nullptr))
         return fail(TL_EINVAL, "surf_kind, kappa and poly must be given together (or all NULL)");
+    if (p->aggregate && p->surf_kind) return fail(TL_EINVAL, "aggregate (penalty term) is built for all-spherical lenses only");
+    if (p->aggregate && p->S > 31) return fail(TL_EINVAL, "aggregate needs S <= 31");
     return TL_OK;
 }
 
@@ -216,10 +218,11 @@ size_t tl_workspace_bytes(const tl_problem *p)
 }
 
 int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, uint8_t *ok, uint8_t *back,
-                 float *opd, double *moments, void *workspace, size_t workspace_bytes, void *stream)
+                 float *opd, float *stacks, double *moments, void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = check_problem(p);
     if (rc) return rc;
+    if (stacks && !p->aggregate) return fail(TL_EINVAL, "the stacks output needs tl_problem.aggregate");
     if (opd && !p->n_index) return fail(TL_EINVAL, "the opd output needs tl_problem.n_index");
     if (p->P == 0) {
         if (moments) {
@@ -240,8 +243,8 @@ int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, 
     hipStream_t st = (hipStream_t)stream;
     tl_problem q = *p;
     if (!opd) q.n_index = nullptr;          // the kernel accumulates the path length only when asked
-    int herr = (p->mode == TL_MODE_FAST) ? tl_fast::api_fwd(q, x, y, cx, cy, ok, back, opd, part, pl.nbx, pl.R, st)
-                                         : tl_strict::api_fwd(q, x, y, cx, cy, ok, back, opd, part, pl.nbx, pl.R, st);
+    int herr = (p->mode == TL_MODE_FAST) ? tl_fast::api_fwd(q, x, y, cx, cy, ok, back, opd, stacks, part, pl.nbx, pl.R, st)
+                                         : tl_strict::api_fwd(q, x, y, cx, cy, ok, back, opd, stacks, part, pl.nbx, pl.R, st);
     if (herr) return hip_fail(herr, "trace_fwd_kernel launch");
     if (moments) {
         hipLaunchKernelGGL(reduce_moments_kernel, dim3(p->F * TL_NMOM), dim3(kBlock), 0, st, part, moments, p->W, pl.nbx);

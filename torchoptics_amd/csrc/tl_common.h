@@ -19,7 +19,8 @@ static inline int tl_bwd_row(int ns, bool asph) { return (asph ? 8 : 3) * ns + 3
 #define TL_DECLARE_MODE(NS)                                                                          \
     namespace NS {                                                                                   \
     int api_fwd(const tl_problem &p, float *x, float *y, float *cx, float *cy, uint8_t *ok,           \
-                uint8_t *back, float *opd, double *part, int nbx, int R, hipStream_t st);            \
+                uint8_t *back, float *opd, float *stacks, double *part, int nbx, int R,             \
+                hipStream_t st);                                                                     \
     int api_bwd(const tl_problem &p, const float *gx, const float *gy, const float *gcx,              \
                 const float *gcy, const double *gmom, float *gxin, float *gyin, double *part,         \
                 int nbx, int R, hipStream_t st);                                                     \

@@ -6,8 +6,8 @@
 #include "tl_kernels.inc"
 namespace tl_fast {
 int api_fwd(const tl_problem &p, float *x, float *y, float *cx, float *cy, uint8_t *ok, uint8_t *back,
-            float *opd, double *part, int nbx, int R, hipStream_t st)
-{ return tl_fast_impl::launch_fwd(p, x, y, cx, cy, ok, back, opd, part, nbx, R, st); }
+            float *opd, float *stacks, double *part, int nbx, int R, hipStream_t st)
+{ return tl_fast_impl::launch_fwd(p, x, y, cx, cy, ok, back, opd, stacks, part, nbx, R, st); }
 int api_bwd(const tl_problem &p, const float *gx, const float *gy, const float *gcx, const float *gcy,
             const double *gmom, float *gxin, float *gyin, double *part, int nbx, int R, hipStream_t st)
 { return tl_fast_impl::launch_bwd(p, gx, gy, gcx, gcy, gmom, gxin, gyin, part, nbx, R, st); }

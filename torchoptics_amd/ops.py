@@ -89,13 +89,14 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa=None, poly=None, kind_u8=None,
-             n_index=None):
+             n_index=None, aggregate=False):
     F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
     p = tl_problem()
     p.F, p.P, p.W, p.S = F, P, W, c.numel()
     p.device = x_e.device.index
     p.mode = _MODES[mode]
     p.allow_backward = 1 if allow_back else 0
+    p.aggregate = 1 if aggregate else 0
     p.x_in, p.y_in = x_e.data_ptr(), y_e.data_ptr()
     p.xs_f, p.xs_p, p.xs_w = x_e.stride(1), x_e.stride(2), x_e.stride(3)
     p.ys_f, p.ys_p, p.ys_w = y_e.stride(1), y_e.stride(2), y_e.stride(3)
@@ -124,7 +125,7 @@ class TraceFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_e, y_e, z, cx, cy, c, t, mu, kappa, poly, mask_u8, kind_u8, n_index, allow_back, mode,
-                want_rays, want_opd):
+                want_rays, want_opd, aggregate, want_stacks):
         for name, ten in (("x", x_e), ("y", y_e), ("z", z), ("cx", cx), ("cy", cy), ("c", c), ("t", t),
                           ("mu", mu), ("mask", mask_u8)):
             _require_device(ten, name)
@@ -134,7 +135,9 @@ class TraceFunction(torch.autograd.Function):
         if S > _lib.TL_MAX_SURFACES:
             raise RuntimeError(f"lens has {S} rows; this build supports at most {_lib.TL_MAX_SURFACES}")
         lib = _lib.lib()
-        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa, poly, kind_u8, n_index)
+        if aggregate and kind_u8 is not None:
+            raise NotImplementedError("aggregate=True (penalty term) is built for all-spherical lenses only")
+        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa, poly, kind_u8, n_index, aggregate)
         nbytes = lib.tl_workspace_bytes(C.byref(prob))
         ws = _workspace(nbytes, dev)
         if want_rays:
@@ -143,13 +146,15 @@ class TraceFunction(torch.autograd.Function):
         else:
             fp, bp = [None] * 4, [None] * 2
         opd = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if want_opd else None
+        stacks = torch.empty((3, S, 1, F, W, P), dtype=torch.float32, device=dev) if (aggregate and want_stacks) else None
         moments = torch.empty((F, TL_NMOM), dtype=torch.float64, device=dev)
         with torch.cuda.device(dev), _Timed("fwd", dev):
             rc = lib.tl_trace_fwd(C.byref(prob), *[_lib.ptr(b) for b in fp], *[_lib.ptr(b) for b in bp],
-                                  _lib.ptr(opd), _lib.ptr(moments), _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
+                                  _lib.ptr(opd), _lib.ptr(stacks), _lib.ptr(moments), _lib.ptr(ws), ws.numel(),
+                                  _stream_ptr(dev))
         _lib.check(rc, "tl_trace_fwd")
         ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8)
-        ctx.allow_back, ctx.mode = allow_back, mode
+        ctx.allow_back, ctx.mode, ctx.aggregate = allow_back, mode, aggregate
         ctx.set_materialize_grads(False)
         if want_rays:
             outs = [b.permute(0, 1, 3, 2) for b in fp]
@@ -158,21 +163,23 @@ class TraceFunction(torch.autograd.Function):
             outs = [torch.empty(0, device=dev) for _ in range(4)]
             flags = [torch.empty(0, dtype=torch.bool, device=dev) for _ in range(2)]
         opd_out = opd.permute(0, 1, 3, 2) if want_opd else torch.empty(0, device=dev)
-        ctx.mark_non_differentiable(*flags, opd_out)
-        return (*outs, *flags, moments, opd_out)
+        stk_out = stacks.permute(0, 1, 2, 3, 5, 4) if stacks is not None else torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(*flags, opd_out, stk_out)
+        return (*outs, *flags, moments, opd_out, stk_out)
 
     @staticmethod
-    def backward(ctx, gx, gy, gcx, gcy, _gok, _gback, gmom, _gopd):
+    def backward(ctx, gx, gy, gcx, gcy, _gok, _gback, gmom, _gopd, _gstk):
         x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8 = ctx.saved_tensors
         dev = x_e.device
         F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
         S = c.numel()
-        n_in = 17
+        n_in = 19
         if gx is None and gy is None and gcx is None and gcy is None and gmom is None:
             return (None,) * n_in
         asph = kind_u8 is not None
         lib = _lib.lib()
-        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, ctx.allow_back, ctx.mode, kappa, poly, kind_u8)
+        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, ctx.allow_back, ctx.mode, kappa, poly, kind_u8,
+                        aggregate=ctx.aggregate)
         ws = _workspace(lib.tl_workspace_bytes(C.byref(prob)), dev)
 
         def dense(g):
@@ -204,7 +211,7 @@ class TraceFunction(torch.autograd.Function):
                 g_z.reshape(z.shape), g_cx.reshape(cx.shape), g_cy.reshape(cy.shape),
                 g_c.reshape(c.shape), g_t.reshape(t.shape), g_mu.reshape(mu.shape),
                 parts[6].reshape(kappa.shape) if asph else None, parts[7].reshape(poly.shape) if asph else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 class SpotMomentsFunction(torch.autograd.Function):

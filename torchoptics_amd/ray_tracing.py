@@ -91,6 +91,9 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
     x, y, z, cx, cy, c, t, mu through a hand-written backward kernel.
 
     Extras (not in the reference):
+      aggregate   True: a 7th return value `stacks` = {'z_RELU', 'theta_norm', 'theta_prime_norm'}, each a
+                  list of S tensors [1,F,P,W] as in the reference (:641-657).  The stacks are plain values;
+                  the differentiable quantity is their fused sum, see `penalty_sum(stacks, n_sequence)`;
       mode        'strict' | 'fast' arithmetic (default ops.get_default_mode());
       kappa, poly aspheric rows: conic constants [S] and even polynomial terms [S,4] (a4..a10);
                   `surf_kind` [S] (bool/int) marks the rows traced by Newton iteration -- default: the
@@ -100,9 +103,6 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
       the returned `y` carries the fused spot moments so `compute_rms2d(x, y, ray_ok)` costs no
       second pass over the rays.
     """
-    if aggregate:
-        raise NotImplementedError("aggregate=True (per-surface penalty stacks) is not built yet; "
-                                  "see DESIGN.md 'next rows'")
     x, y, z, cx, cy = (_as_f32(a, n) for a, n in ((x, 'x'), (y, 'y'), (z, 'z'), (cx, 'cx'), (cy, 'cy')))
     c, t, mu = _as_f32(c, 'c'), _as_f32(t, 't'), _as_f32(mu, 'mu')
     for a, n in ((x, 'x'), (y, 'y'), (cx, 'cx'), (cy, 'cy'), (z, 'z')):
@@ -138,13 +138,51 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
         nidx = _as_f32(n_index, 'n_index').reshape(-1, S + 1).expand(W, S + 1).contiguous()
     out = ops.TraceFunction.apply(x_e, y_e, z.reshape(1).contiguous(), cxv, cyv, c.reshape(S).contiguous(),
                                   t.reshape(S).contiguous(), mu2, kap, pol, mask_u8, kind_u8, nidx,
-                                  bool(allow_backward_rays), mode or ops.get_default_mode(), want_rays, bool(want_opd))
-    xo, yo, cxo, cyo, ok, back, moments, opd = out
+                                  bool(allow_backward_rays), mode or ops.get_default_mode(), want_rays, bool(want_opd),
+                                  bool(aggregate), bool(aggregate and want_rays))
+    xo, yo, cxo, cyo, ok, back, moments, opd, stk = out
     if want_rays:
         # remember which moments belong to these rays (checked by identity + version in compute_rms2d)
         yo._tl_spot = (moments, ok, yo._version, P * W)
-        return (xo, yo, cxo, cyo, ok, back, opd) if want_opd else (xo, yo, cxo, cyo, ok, back)
+        res = (xo, yo, cxo, cyo, ok, back)
+        if want_opd:
+            res += (opd,)
+        if aggregate:
+            res += (PenaltyStacks(stk, moments),)
+        return res
     return moments
+
+
+class PenaltyStacks(dict):
+    """The `stacks` dict of trace_skew(aggregate=True): three lists of S per-surface tensors, plus
+    `q_sum` = sum over all rays of (sum theta + sum theta' + sum z_RELU) with NaN -> 0, fused into the
+    trace kernel and differentiable through its backward kernel (the lists themselves are values only)."""
+
+    def __init__(self, stk, moments):
+        super().__init__()
+        for j, key in enumerate(('z_RELU', 'theta_norm', 'theta_prime_norm')):
+            self[key] = list(torch.unbind(stk[j], dim=0))
+        self.q_sum = moments[:, 8].sum()
+
+
+def penalty_sum(stacks, n_sequence: int):
+    """sumQ of the reference's compute_loss_out (optics_simulator_lite.py:441-448):
+    Q = (sum_k theta + sum_k theta' + sum_k z_RELU) / n_sequence per ray, NaN -> 0, summed over rays."""
+    if isinstance(stacks, PenaltyStacks):
+        return (stacks.q_sum / n_sequence).to(torch.float32)
+    q = (torch.stack(stacks['theta_norm'], 0).sum(0) + torch.stack(stacks['theta_prime_norm'], 0).sum(0)
+         + torch.stack(stacks['z_RELU'], 0).sum(0)) / n_sequence
+    return torch.where(torch.isnan(q), torch.zeros_like(q), q).sum()
+
+
+def unsupervised_loss(rt_outputs, n_sequence: int, penalty_rate: float):
+    """loss_dict of the reference's RaytracedOptics.compute_loss_out (optics_simulator_lite.py:430-450):
+    {'loss_unsup': rms + penalty_rate * sumQ, 'rms': rms, 'penalty': sumQ} from the 7-tuple that
+    trace_rays(..., aggregate=True) returns."""
+    x, y, *_, ray_ok, _ray_backward, stacks = rt_outputs
+    rms = compute_rms2d(x, y, ray_ok)
+    pen = penalty_sum(stacks, n_sequence)
+    return {'loss_unsup': rms + penalty_rate * pen, 'rms': rms, 'penalty': pen}
 
 
 def rms_from_moments(moments: torch.Tensor, n_per_field: int) -> torch.Tensor:
