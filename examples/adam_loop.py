@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""
+cfg5 of BASELINE.json: an Adam optimisation loop on the lens parameters (curvatures and thicknesses)
+of the 20-row synthetic zoom, 5 fields x 3 wavelengths, every step = forward + RMS spot + backward
+through the HIP kernels; the pupil is sharded over the GPUs of one node.
+
+    python examples/adam_loop.py --steps 100                       # 1 GPU
+    python -m torch.distributed.run --nproc-per-node 8 examples/adam_loop.py --steps 100
+
+The optimiser state lives on the device and nothing in the loop synchronises with the host except
+the final report; per step and rank: 1 forward kernel, 1 all-reduce of [F,10] doubles, 1 backward
+kernel, 1 all-reduce of the packed leaf gradients, Adam on < 100 scalars.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(steps=100, lr=2e-4, log2_pupil=20, workload="zoom20", device="cuda:0", group=None, rank=0, world=1,
+        arith="strict", verbose=False, graph=False):
+    import torchoptics_amd as ta
+    from torchoptics_amd import dist as tl_dist, prescriptions as P, ray_tracing as rt
+    lens_fn = {"zoom20": P.zoom20, "double_gauss": P.double_gauss}[workload]
+    lens0, specs, leaves = lens_fn(device)
+    fields = tuple(np.linspace(0, 1, 5)) if workload == "zoom20" else (0., 0.707, 1.)
+    wl = ("C", "d", "F")
+    p_local = 1 << log2_pupil
+    n_r = 1 << (log2_pupil // 2)
+    n_theta = (p_local // n_r) * world
+    tracer = ta.RayTracer(mode="circular", n_rays=(n_r, n_theta), rel_fields=fields, wavelengths=wl,
+                          default_device=device, arith=arith)
+    xy = rt.circle_index_range(n_r, n_theta, rank * p_local, (rank + 1) * p_local, device)
+    params = [leaves["c"], leaves["t"]]
+    opt = torch.optim.Adam(params, lr=lr, capturable=graph)
+    n_per_field = p_local * world * len(wl)
+    history = []
+
+    def one_step():
+        opt.zero_grad(set_to_none=True)
+        lens = ta.Lens(lens0.structure, leaves["c"], leaves["t"], leaves["nd"].detach(), leaves["v"].detach())
+        x, y, cx, cy, ok, back = tracer.trace_rays(specs, lens, xy=xy)
+        loss = rt.compute_rms2d(x, y, ok, group=group, n_per_field=n_per_field)
+        loss.backward()
+        if group is not None:
+            tl_dist.all_reduce_grads(params, group)
+        opt.step()
+        return loss.detach()
+
+    history.append(one_step())          # warm-up (allocations), also the initial loss
+    torch.cuda.synchronize()
+    if graph:
+        raise NotImplementedError(
+            "whole-step HIP-graph capture is disabled: on PyTorch 2.10+rocm7.0 hipStreamEndCapture segfaults as soon "
+            "as the captured region holds an ordinary autograd backward of the host chain (reproduced with "
+            "(p.sum()*2 + q.pow(2).sum()).backward() alone).  The trace kernels themselves capture and replay "
+            "correctly, see tests/test_gpu_adam_loop.py::test_trace_kernels_capture_in_a_hip_graph.")
+    else:
+        t0 = time.perf_counter()
+        for i in range(steps):
+            history.append(one_step())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    losses = torch.stack(history).cpu().tolist()
+    rays = len(fields) * len(wl) * p_local * world
+    out = dict(workload=workload, rows=int(lens0.c.shape[1]), fields=len(fields), wavelengths=len(wl), rays_per_step=rays,
+               n_gpus=world, steps=steps, steps_per_s=steps / dt, M_rays_per_s=rays * steps / dt / 1e6,
+               loss_initial=losses[0], loss_final=losses[-1], arith_mode=arith, hip_graph=bool(graph))
+    if verbose and rank == 0:
+        print(json.dumps(out))
+    return out, losses
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--lr", type=float, default=2e-4)
+    ap.add_argument("--log2-pupil", type=int, default=20)
+    ap.add_argument("--workload", default="zoom20", choices=["zoom20", "double_gauss"])
+    ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--graph", action="store_true", help="(disabled, see run()) capture the whole step in a HIP graph")
+    a = ap.parse_args()
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group("gloo")
+        group = dist.group.WORLD
+    run(a.steps, a.lr, a.log2_pupil, a.workload, f"cuda:{local}", group, rank, world, a.mode, verbose=True, graph=a.graph)
+    if group is not None:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

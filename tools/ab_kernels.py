@@ -53,14 +53,21 @@ def main():
     for spec in a.libs:
         name, path = spec.split("=")
         dll = C.CDLL(os.path.join(ROOT, path))
+        dll.tl_version.restype = C.c_int
+        ver = dll.tl_version()
         for fn, (res, argt) in _lib._SIGNATURES.items():
             f = getattr(dll, fn)
-            f.restype, f.argtypes = res, argt
+            f.restype = res
+            if fn == "tl_trace_fwd" and ver < 5:       # older ABI: no `stacks` argument
+                argt = argt[:8] + argt[9:]
+            f.argtypes = argt
+        dll._ver = ver
         libs[name] = dll
     P_ = _lib.ptr
 
     def fwd(dll):
-        rc = dll.tl_trace_fwd(C.byref(prob), *[P_(o) for o in outs], *[P_(f) for f in flags], None, None, P_(mom), P_(ws),
+        extra = (None, None) if dll._ver >= 5 else (None,)
+        rc = dll.tl_trace_fwd(C.byref(prob), *[P_(o) for o in outs], *[P_(f) for f in flags], *extra, P_(mom), P_(ws),
                               ws.numel(), st)
         assert rc == 0, dll.tl_last_error()
 

@@ -22,6 +22,21 @@ import torch
 # Fraunhofer lines used by the two-term dispersion model [nm] (lens_modeling.py:362-364)
 _LAMBDA_C, _LAMBDA_D, _LAMBDA_F = 656.3, 587.6, 486.1
 
+# Small constant tensors are built once per (value, dtype, device): the per-step host chain must not
+# issue host-to-device copies, otherwise it cannot be captured in a HIP graph (and each is a sync).
+_CONST = {}
+
+
+def const_tensor(values, dtype, device, shape=None):
+    key = (tuple(np.ravel(values).tolist()), dtype, str(device), shape)
+    t = _CONST.get(key)
+    if t is None:
+        t = torch.tensor(values, dtype=dtype)
+        if shape is not None:
+            t = t.reshape(shape)
+        t = _CONST[key] = t.to(device)
+    return t
+
 
 def mask_replace(mask: np.ndarray, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     """Write the 1-D `dst` into `src` where `mask` is set (row-major order)."""
@@ -83,16 +98,25 @@ class Structure:
         self.default_device = default_device
         self.mask_torch = torch.from_numpy(np.ascontiguousarray(self.mask)).to(default_device)
         self.mask_G_torch = torch.from_numpy(np.ascontiguousarray(self.mask_G)).to(default_device)
+        # flat positions of the real rows / the glass rows in the row-major padded layout: gathers and
+        # scatters by index need no device->host synchronisation (boolean-mask indexing does), so the
+        # per-step host chain stays capturable in a HIP graph
+        self.idx_rows = torch.from_numpy(np.flatnonzero(self.mask)).to(default_device)
+        self.idx_glass = torch.from_numpy(np.flatnonzero(self.mask_G)).to(default_device)
 
     def __len__(self):
         return self.mask.shape[0]
 
     def up_to_stop(self) -> "Structure":
-        """The rows in front of the aperture stop (used to locate the entrance pupil)."""
-        width = int(self.stop_idx.max())
-        before = np.arange(width)[None, :] < self.stop_idx[:, None]
-        return Structure(self.stop_idx, self.mask[:, :width] & before, self.mask_G[:, :width] & before,
-                         default_device=self.default_device)
+        """The rows in front of the aperture stop (used to locate the entrance pupil).  Memoised: a
+        Structure is immutable, and building one uploads its masks to the device."""
+        cached = getattr(self, "_up_to_stop", None)
+        if cached is None:
+            width = int(self.stop_idx.max())
+            before = np.arange(width)[None, :] < self.stop_idx[:, None]
+            cached = self._up_to_stop = Structure(self.stop_idx, self.mask[:, :width] & before,
+                                                  self.mask_G[:, :width] & before, default_device=self.default_device)
+        return cached
 
     def clone(self) -> "Structure":
         return Structure(self.stop_idx.copy(), self.mask.copy(), self.mask_G.copy(), default_device=self.default_device)
@@ -154,9 +178,17 @@ class Specs:
                      self.vig_down[index], self.vig_x[index])
 
 
-def _pad_from_flat(flat: torch.Tensor, mask_t: torch.Tensor, fill: float) -> torch.Tensor:
-    base = torch.full(tuple(mask_t.shape), fill, dtype=flat.dtype, device=mask_t.device)
-    return base.masked_scatter(mask_t, flat)
+def _pad_from_flat(flat: torch.Tensor, mask_t: torch.Tensor, fill: float, idx: torch.Tensor) -> torch.Tensor:
+    """flat [n] (or [n, k]) -> padded [lens, row] (or [lens, row, k]) with `fill` elsewhere."""
+    tail = tuple(flat.shape[1:])
+    base = torch.full((mask_t.numel(), *tail), fill, dtype=flat.dtype, device=mask_t.device)
+    return base.index_copy(0, idx, flat.to(mask_t.device)).reshape(*mask_t.shape, *tail)
+
+
+def _take(padded: torch.Tensor, width: int, idx: torch.Tensor) -> torch.Tensor:
+    """The entries `idx` (flat positions in the [lens, width] layout) of padded[:, :width(, k)]."""
+    cut = padded[:, :width]
+    return cut.reshape(cut.shape[0] * width, *cut.shape[2:]).index_select(0, idx)
 
 
 @dataclass
@@ -182,19 +214,17 @@ class Lens:
                 self.poly = torch.zeros(n_rows, 4, dtype=ref.dtype, device=ref.device)
         if self.kappa is not None:
             if self.kappa.dim() == 1:
-                self.kappa = _pad_from_flat(self.kappa, st.mask_torch, 0.0)
+                self.kappa = _pad_from_flat(self.kappa, st.mask_torch, 0.0, st.idx_rows)
             if self.poly.dim() == 2:                 # flat [rows, 4] -> padded [lens, row, 4]
-                flat = self.poly
-                base = torch.zeros((*st.mask.shape, 4), dtype=flat.dtype, device=st.mask_torch.device)
-                self.poly = base.masked_scatter(st.mask_torch[..., None].expand_as(base), flat)
+                self.poly = _pad_from_flat(self.poly, st.mask_torch, 0.0, st.idx_rows)
         if self.c.dim() == 1:
-            self.c = _pad_from_flat(self.c, st.mask_torch, 0.0)
+            self.c = _pad_from_flat(self.c, st.mask_torch, 0.0, st.idx_rows)
         if self.t.dim() == 1:
-            self.t = _pad_from_flat(self.t, st.mask_torch, 0.0)
+            self.t = _pad_from_flat(self.t, st.mask_torch, 0.0, st.idx_rows)
         if self.nd.dim() == 1:
-            self.nd = _pad_from_flat(self.nd, st.mask_G_torch, 1.0)
+            self.nd = _pad_from_flat(self.nd, st.mask_G_torch, 1.0, st.idx_glass)
         if self.v.dim() == 1:
-            self.v = _pad_from_flat(self.v, st.mask_G_torch, float('nan'))
+            self.v = _pad_from_flat(self.v, st.mask_G_torch, float('nan'), st.idx_glass)
 
     def __len__(self):
         return len(self.structure)
@@ -212,9 +242,9 @@ class Lens:
     def up_to_stop(self) -> "Lens":
         st = self.structure.up_to_stop()
         n = st.mask.shape[1]
-        kap, pol = self._asph(lambda a: a[:, :n][st.mask_torch])
-        return Lens(st, self.c[:, :n][st.mask_torch], self.t[:, :n][st.mask_torch],
-                    self.nd[:, :n][st.mask_G_torch], self.v[:, :n][st.mask_G_torch], kap, pol)
+        kap, pol = self._asph(lambda a: _take(a, n, st.idx_rows))
+        return Lens(st, _take(self.c, n, st.idx_rows), _take(self.t, n, st.idx_rows),
+                    _take(self.nd, n, st.idx_glass), _take(self.v, n, st.idx_glass), kap, pol)
 
     def __getitem__(self, index) -> "Lens":
         index = slice(index, index + 1) if isinstance(index, int) else index
@@ -282,7 +312,7 @@ class Lens:
         """
         b = (self.nd - 1) / (self.v * (_LAMBDA_F ** -2 - _LAMBDA_C ** -2))
         a = self.nd - b / _LAMBDA_D ** 2
-        lam = torch.tensor([[list(wavelengths)]], dtype=a.dtype).to(a.device)
+        lam = const_tensor(list(wavelengths), a.dtype, a.device, (1, 1, len(wavelengths)))
         n = a[..., None] + b[..., None] / lam ** 2
         n = torch.where(self.structure.mask_G_torch[..., None], n, torch.ones_like(n))
         dispersive = (self.v != 0)[..., None]

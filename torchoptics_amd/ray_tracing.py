@@ -265,9 +265,10 @@ class RayTracer:
         if self.n_ray_aiming_iter > 0 and not up_to_stop:
             aim = self.ray_aiming(specs, lens.detach(), use_vig)
             xp_rel, yp_rel = (torch.clamp(v, -2, 2).to(dev).detach() for v in aim(xp_rel, yp_rel))
-        fields = torch.tensor(self.rel_fields, dtype=torch.float32).to(dev)
+        from .lens_modeling import const_tensor
+        fields = const_tensor(list(self.rel_fields), torch.float32, dev)
         cy = torch.sin((specs.hfov[:, None] * fields[None, :])[..., None, None])
-        cx = torch.zeros(1, device=dev).reshape(1, 1, 1, 1)
+        cx = const_tensor([0.0], torch.float32, dev, (1, 1, 1, 1))
         out = dict(
             x=scale_to_epd(xp_rel.to(dev), specs.epd), y=scale_to_epd(yp_rel.to(dev), specs.epd), z=z, cx=cx, cy=cy,
             c=lens.c.reshape(lens.c.shape[0], 1, 1, 1, -1), t=lens.t.reshape(lens.t.shape[0], 1, 1, 1, -1),
