@@ -55,6 +55,10 @@ def parse():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the secondary measurement of the other arithmetic mode")
     ap.add_argument("--no-also", action="store_true", help="skip the extra workloads reported next to the main one")
+    ap.add_argument("--graph", action="store_true",
+                    help="record one step (both kernels + reductions + closed form + autograd bookkeeping) into a HIP "
+                         "graph and time replays of it instead of eager steps")
+    ap.add_argument("--no-graph-child", action="store_true", help="skip the secondary HIP-graph measurement (child process)")
     ap.add_argument("--cpu-log2-rays", type=int, default=20, help="log2 of the CPU-baseline sample (rays)")
     return ap.parse_args()
 
@@ -97,7 +101,7 @@ def pmc_traffic(workload_name, mode, kernel, meta):
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             d = json.load(f)
-        if meta["P_local"] != (1 << 24) and workload_name == "cfg3":
+        if meta["P_local"] != (1 << 24):
             return None
         return d[workload_name][mode][kernel]["hbm_bytes"]
     except (OSError, KeyError, ValueError):
@@ -166,17 +170,38 @@ def main():
     def timed(mode):
         """W untimed warm-up steps, then exactly K steps between barrier+synchronize; max over ranks."""
         ops.set_default_mode(mode)
-        for _ in range(a.warmup):
-            r = step()
-        sync()
-        ops.enable_timing(True)
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            r = step()
-        sync()
-        el = time.perf_counter() - t0
-        km = ops.timing_ms()
-        ops.enable_timing(False)
+        if a.graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(a.warmup, 3)):
+                    r = step()
+            torch.cuda.current_stream().wait_stream(side)
+            for p_ in leaves:
+                p_.grad = None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                r = step()
+            for _ in range(a.warmup):
+                g.replay()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                g.replay()
+            sync()
+            el, km = time.perf_counter() - t0, {}
+        else:
+            for _ in range(a.warmup):
+                r = step()
+            sync()
+            ops.enable_timing(True)
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                r = step()
+            sync()
+            el = time.perf_counter() - t0
+            km = ops.timing_ms()
+            ops.enable_timing(False)
         if group is not None:
             tmax = torch.tensor([el], dtype=torch.float64, device="cpu" if a.backend == "gloo" else device)
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -240,6 +265,27 @@ def main():
                                F=meta2["F"], W=meta2["W"], rms=float(arms.item()), arith_mode=a.mode)
         args, meta, leaves, asph, n_per_field_total = main_state
 
+    # the same step replayed from a HIP graph, measured in a CHILD process (a capture failure of the
+    # PyTorch/ROCm stack must not cost the main line); N = 1 only
+    hip_graph = None
+    if world == 1 and not a.graph and not a.no_graph_child:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--graph", "--steps", str(a.steps), "--warmup", str(a.warmup),
+               "--workload", a.workload, "--mode", a.mode, "--no-cpu-baseline", "--no-other-mode", "--no-also"]
+        if a.log2_pupil is not None:
+            cmd += ["--log2-pupil", str(a.log2_pupil)]
+        try:
+            cp = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+            line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            if cp.returncode == 0 and line:
+                child = json.loads(line[-1])
+                hip_graph = dict(value=child["value"], unit="M rays/s", ms_per_step=child["ms_per_step"],
+                                 note="the identical step recorded once into a HIP graph and replayed")
+            else:
+                hip_graph = dict(error=f"child exited with {cp.returncode}")
+        except Exception as e:       # timeout or launch failure
+            hip_graph = dict(error=repr(e))
+
     cpu_baseline, grad_check = None, None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu_baseline, grad_check = cpu_leg(args, meta, a.cpu_log2_rays, a.mode)
@@ -253,11 +299,13 @@ def main():
             "config": {"workload": f"{a.workload}: {meta['lens']} S={meta['S']} rows, F={meta['F']} W={meta['W']} "
                                    f"P={meta['P_local']} pupil points per GPU ({rays_local} rays/GPU, {rays_total} total), "
                                    f"circular grid, loss=compute_rms2d, fwd+bwd",
-                       "arith_mode": a.mode, "parallelism": f"pupil-sharded dp{world}", "rms": float(rms.item())},
+                       "arith_mode": a.mode, "parallelism": f"pupil-sharded dp{world}", "rms": float(rms.item()),
+                       "hip_graph": bool(a.graph)},
             "roofline": roofline, "roofline_valu": roofline_valu, "kernels": kernels,
             "step_hbm_GBs": step_bytes / (dt / a.steps) / 1e9,
             "grad_rel_err_vs_pytorch_autograd": grad_check,
             "other_mode": other,
+            "hip_graph_replay": hip_graph,
             "also": also,
             "cpu_baseline": cpu_baseline,
         }
