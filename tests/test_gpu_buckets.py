@@ -1,0 +1,141 @@
+"""
+Every compile-time row bucket of the kernels (NS = 4, 8, 12, 16, 20, 24, 32) against the oracle:
+strict forward bit-exact, gradients within 1e-5 of the oracle's fp32 (IEEE sqrt) autograd or 2x its
+distance from fp64.  Lenses: truncations / extensions of the synthetic 20-row prescription (extra rows
+are flat air/air dummies with a small gap, which every ray passes undeviated).
+Also: C-ABI error paths and concurrent use from two host threads.
+"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import torchoptics_amd
+    from torchoptics_amd import _lib
+    _lib.lib()
+    return torchoptics_amd
+
+
+def lens_args(ta, n_rows, n_rays=(16, 16)):
+    """Kernel arguments for the first `n_rows` rows of zoom20 (n_rows <= 20) or zoom20 + dummies."""
+    from torchoptics_amd import prescriptions as P
+    lens, specs, leaves = P.zoom20("cpu", requires_grad=False)
+    tr = ta.RayTracer(mode="circular", n_rays=n_rays, rel_fields=(0., 0.6, 1.), wavelengths=("C", "d", "F"),
+                      default_device="cpu")
+    a = tr.assemble(specs, lens)
+    S = a["c"].shape[-1]
+    if n_rows <= S:
+        for k in ("c", "t", "mu", "mask"):
+            a[k] = a[k][..., :n_rows].contiguous()
+        if n_rows < S:                      # image plane right behind the last kept row
+            a["t"] = a["t"].clone()
+            a["t"][..., -1] = 0.5
+    else:
+        extra = n_rows - S
+        t_last = a["t"][..., -1:].clone()
+        a["c"] = torch.cat((a["c"], torch.zeros(1, 1, 1, 1, extra)), -1)
+        a["mu"] = torch.cat((a["mu"], torch.ones(1, 1, 1, a["mu"].shape[3], extra)), -1)
+        a["mask"] = torch.cat((a["mask"], torch.ones(1, 1, 1, 1, extra, dtype=torch.bool)), -1)
+        gaps = torch.full((1, 1, 1, 1, extra), 0.05)
+        a["t"] = torch.cat((a["t"][..., :-1], gaps, t_last - 0.05 * extra), -1)
+    return a
+
+
+@pytest.mark.parametrize("n_rows", [2, 4, 5, 8, 9, 12, 13, 16, 17, 20, 21, 24, 25, 28, 32])
+def test_every_row_bucket_matches_oracle(ta, n_rows):
+    from oracle import trace_oracle as orc
+    a = lens_args(ta, n_rows)
+    order = ("x", "y", "z", "cx", "cy", "c", "t", "mu")
+    want = orc.trace_skew(*[a[k] for k in order], a["mask"], ieee_sqrt=True)
+    dev = {k: v.to(DEV) for k, v in a.items()}
+    lv = {k: dev[k].clone().requires_grad_(True) for k in ("z", "cy", "c", "t", "mu")}
+    args = [lv.get(k, dev[k]) for k in order]
+    got = ta.trace_skew(*args, dev["mask"], mode="strict")
+    for name, g_, w_ in zip(("x", "y", "cx", "cy", "ok", "back"), got, want):
+        assert torch.equal(g_.cpu(), w_), f"S={n_rows}: {name} not bit-exact"
+    assert got[4].float().mean().item() > 0.5
+    ta.compute_rms2d(got[0], got[1], got[4]).backward()
+    ref = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        cl = {k: a[k].to(dt).clone().requires_grad_(True) for k in lv}
+        o = orc.trace_skew(*[cl.get(k, a[k].to(dt)) for k in order], a["mask"], ieee_sqrt=(dt == torch.float32))
+        orc.compute_rms2d(o[0], o[1], o[4]).backward()
+        ref[tag] = {k: v.grad for k, v in cl.items()}
+    for k in ("c", "t", "mu"):
+        g = lv[k].grad.cpu().numpy()
+        e32, e64 = rel_l2(g, ref["f32"][k].numpy()), rel_l2(g, ref["f64"][k].numpy())
+        noise = rel_l2(ref["f32"][k].numpy(), ref["f64"][k].numpy())
+        assert e32 <= 1e-5 or e64 <= 2 * noise + 1e-6, f"S={n_rows} d/d{k}: vs fp32 {e32:.2e}, vs fp64 {e64:.2e}, noise {noise:.2e}"
+
+
+def test_more_than_32_rows_is_refused(ta):
+    a = lens_args(ta, 33)
+    order = ("x", "y", "z", "cx", "cy", "c", "t", "mu")
+    with pytest.raises(RuntimeError, match="at most 32"):
+        ta.trace_skew(*[a[k].to(DEV) for k in order], a["mask"].to(DEV))
+
+
+def test_cabi_error_codes(ta):
+    """Bad arguments come back as negative codes with a message; nothing is launched."""
+    import ctypes as C
+    from torchoptics_amd import _lib
+    lib = _lib.lib()
+    p = _lib.tl_problem()
+    assert lib.tl_trace_fwd(None, *([None] * 9), None, 0, None) == -1
+    assert b"NULL" in lib.tl_last_error()
+    p.F, p.P, p.W, p.S, p.device = 1, 64, 1, 40, 0
+    assert lib.tl_trace_fwd(C.byref(p), *([None] * 9), None, 0, None) == -1
+    assert b"TL_MAX_SURFACES" in lib.tl_last_error()
+    p.S = 3
+    assert lib.tl_trace_fwd(C.byref(p), *([None] * 9), None, 0, None) == -1       # required pointers are NULL
+    buf = torch.zeros(64, device=DEV)
+    m8 = torch.ones(8, dtype=torch.uint8, device=DEV)
+    for f in ("x_in", "y_in", "z", "cx", "cy", "c", "t", "mu"):
+        setattr(p, f, buf.data_ptr())
+    p.mask = m8.data_ptr()
+    p.xs_p = p.ys_p = 1
+    p.mode = 7
+    assert lib.tl_trace_fwd(C.byref(p), *([None] * 9), None, 0, None) == -1 and b"mode" in lib.tl_last_error()
+    p.mode = 0
+    mom = torch.zeros(1, _lib.TL_NMOM, dtype=torch.float64, device=DEV)
+    assert lib.tl_trace_fwd(C.byref(p), *([None] * 8), _lib.ptr(mom), None, 0, None) == -3      # workspace too small
+    p.surf_kind = m8.data_ptr()                                                     # kappa / poly missing
+    assert lib.tl_trace_fwd(C.byref(p), *([None] * 9), None, 0, None) == -1
+    torch.cuda.synchronize()
+
+
+def test_two_host_threads_share_the_library(ta):
+    """The C ABI keeps no mutable global state: two Python threads trace different lenses at once
+    (each on its own stream) and both get the single-thread answer."""
+    from oracle import trace_oracle as orc
+    order = ("x", "y", "z", "cx", "cy", "c", "t", "mu")
+    cases = [lens_args(ta, 8, (32, 32)), lens_args(ta, 20, (32, 32))]
+    want = [orc.trace_skew(*[a[k] for k in order], a["mask"], ieee_sqrt=True) for a in cases]
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                dev = {k: v.to(DEV) for k, v in cases[i].items()}
+                for _ in range(20):
+                    out = ta.trace_skew(*[dev[k] for k in order], dev["mask"], mode="strict")
+                stream.synchronize()
+                results[i] = [o.cpu() for o in out]
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for got, w in zip(results, want):
+        assert all(torch.equal(g_, w_) for g_, w_ in zip(got, w))
