@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 5
+#define TL_ABI_VERSION 6
 #define TL_MAX_SURFACES 32       /* rows per lens the backward kernels are built for */
 #define TL_NMOM 10               /* per-field sums, see tl_trace_fwd */
 #define TL_MAX_POLY 4            /* even aspheric terms a4,a6,a8,a10 */
@@ -115,16 +115,17 @@ int tl_trace_fwd(const tl_problem *p,
  *   g_moments     : [F,TL_NMOM] double upstream gradient of `moments` (nullable); the per-ray
  *                   seed  gM0 + ok*(gM1 + 2*y*gM2)  (and the x analogue) is formed in-kernel;
  *                   entry 8 seeds the penalty term when p->aggregate
- *   g_c,g_t [S], g_mu [W,S], g_z [1], g_cx,g_cy [F] : double, OVERWRITTEN (not accumulated)
- *   g_kappa [S], g_poly [S,TL_MAX_POLY] : double, nullable (aspheric extension)
+ *   g_c,g_t [S], g_mu [W,S], g_z [1], g_cx,g_cy [F] : float, OVERWRITTEN (not accumulated); summed over the
+ *                   rays in fp64 in a fixed order and rounded once
+ *   g_kappa [S], g_poly [S,TL_MAX_POLY] : float, nullable (aspheric extension)
  *   g_x_in,g_y_in : [F,W,P] float per-ray input gradients (nullable; used by ray aiming,
  *                   ray_tracing_lite.py:169-181)
  */
 int tl_trace_bwd(const tl_problem *p,
                  const float *gx, const float *gy, const float *gcx, const float *gcy,
                  const double *g_moments,
-                 double *g_c, double *g_t, double *g_mu, double *g_z, double *g_cx, double *g_cy,
-                 double *g_kappa, double *g_poly,
+                 float *g_c, float *g_t, float *g_mu, float *g_z, float *g_cx, float *g_cy,
+                 float *g_kappa, float *g_poly,
                  float *g_x_in, float *g_y_in,
                  void *workspace, size_t workspace_bytes, void *stream);
 
@@ -137,6 +138,15 @@ int tl_spot_moments(int32_t device, int32_t F, int32_t P, int32_t W,
                     const float *x, const float *y, const uint8_t *ok,
                     int64_t s_f, int64_t s_p, int64_t s_w,
                     double *moments, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * The closed form of compute_rms2d (ray_tracing_lite.py:684-701) on the moments, and its derivative:
+ *   rms = mean_f sqrt((M2 - 2 m M1 + m^2 M3) / n),  m = M0 / n,  n = P*W rays per field (of the WHOLE
+ *   pupil when it is sharded over GPUs: pass the all-reduced moments).
+ *   rms [1] float; d_moments [F,TL_NMOM] double = d rms / d moments (zero where the variance is 0).
+ */
+int tl_spot_rms(int32_t device, int32_t F, double n_per_field, const double *moments, float *rms, double *d_moments,
+                void *stream);
 
 /* d(loss)/dy, d(loss)/dx per ray from d(loss)/d(moments); outputs [F,P,W]-strided like y. */
 int tl_spot_seed(int32_t device, int32_t F, int32_t P, int32_t W,

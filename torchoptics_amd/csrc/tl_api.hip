@@ -115,15 +115,15 @@ __global__ __launch_bounds__(kBlock) void reduce_moments_kernel(const double *__
 }
 
 __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__restrict__ part, int NS, int F,
-                                                            int W, int S, int nbx, double *__restrict__ g_c,
-                                                            double *__restrict__ g_t, double *__restrict__ g_mu,
-                                                            double *__restrict__ g_z, double *__restrict__ g_cx,
-                                                            double *__restrict__ g_cy, int ncol,
-                                                            double *__restrict__ g_kappa, double *__restrict__ g_poly)
+                                                            int W, int S, int nbx, float *__restrict__ g_c,
+                                                            float *__restrict__ g_t, float *__restrict__ g_mu,
+                                                            float *__restrict__ g_z, float *__restrict__ g_cx,
+                                                            float *__restrict__ g_cy, int ncol,
+                                                            float *__restrict__ g_kappa, float *__restrict__ g_poly)
 {
     __shared__ double sm[kBlock];
     int b = blockIdx.x;
-    double *out;
+    float *out;
     int col, f0 = 0, nf = F, w0 = 0, nw = W;
     if (b < S) { col = b; out = g_c + b; }
     else if ((b -= S) < S) { col = NS + b; out = g_t + b; }
@@ -134,7 +134,31 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
     else if ((b -= F) < S) { col = 3 * NS + 3 + b; out = g_kappa + b; }                 // aspheric rows only
     else { b -= S; col = 4 * NS + 3 + b; out = g_poly + b; }                             // b = 4k + j
     const double s = sum_rows(part, ncol, col, W, nbx, f0, nf, w0, nw, sm);
-    if (threadIdx.x == 0) *out = s;
+    if (threadIdx.x == 0) *out = (float)s;        // summed in fp64, rounded once
+}
+
+// rms = mean_f sqrt((M2 - 2 m M1 + m^2 M3)/n), m = M0/n  (compute_rms2d on the moments)
+// and d rms / d moments, in one block: replaces ~25 tiny elementwise kernels of the autograd graph.
+__global__ __launch_bounds__(64) void spot_rms_kernel(const double *__restrict__ mom, int F, double n,
+                                                      float *__restrict__ rms, double *__restrict__ dmom)
+{
+    double acc = 0.0;
+    for (int f = threadIdx.x; f < F; f += 64) {
+        const double *M = mom + (size_t)f * TL_NMOM;
+        const double m = M[0] / n;
+        const double var = (M[2] - 2.0 * m * M[1] + m * m * M[3]) / n;
+        const double sd = sqrt(var);
+        acc += sd;
+        const double k = var > 0.0 ? 1.0 / (2.0 * (double)F * n * sd) : 0.0;
+        double *D = dmom + (size_t)f * TL_NMOM;
+        for (int j = 0; j < TL_NMOM; ++j) D[j] = 0.0;
+        D[0] = k * (-2.0 * M[1] + 2.0 * m * M[3]) / n;
+        D[1] = -2.0 * m * k;
+        D[2] = k;
+        D[3] = m * m * k;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (threadIdx.x == 0) *rms = (float)(acc / (double)F);
 }
 
 // ---------------------------------------------------------------- spot kernels (strided tensors)
@@ -255,8 +279,8 @@ int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, 
 }
 
 int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const float *gcx, const float *gcy,
-                 const double *g_moments, double *g_c, double *g_t, double *g_mu, double *g_z, double *g_cx,
-                 double *g_cy, double *g_kappa, double *g_poly, float *g_x_in, float *g_y_in, void *workspace,
+                 const double *g_moments, float *g_c, float *g_t, float *g_mu, float *g_z, float *g_cx,
+                 float *g_cy, float *g_kappa, float *g_poly, float *g_x_in, float *g_y_in, void *workspace,
                  size_t workspace_bytes, void *stream)
 {
     int rc = check_problem(p);
@@ -269,10 +293,10 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     if (p->P == 0) {
         const size_t S = p->S;
-        if ((e = hipMemsetAsync(g_c, 0, S * 8, st)) || (e = hipMemsetAsync(g_t, 0, S * 8, st)) ||
-            (e = hipMemsetAsync(g_mu, 0, S * p->W * 8, st)) || (e = hipMemsetAsync(g_z, 0, 8, st)) ||
-            (e = hipMemsetAsync(g_cx, 0, (size_t)p->F * 8, st)) || (e = hipMemsetAsync(g_cy, 0, (size_t)p->F * 8, st)) ||
-            (g_kappa && (e = hipMemsetAsync(g_kappa, 0, S * 8, st))) || (g_poly && (e = hipMemsetAsync(g_poly, 0, S * 32, st))))
+        if ((e = hipMemsetAsync(g_c, 0, S * 4, st)) || (e = hipMemsetAsync(g_t, 0, S * 4, st)) ||
+            (e = hipMemsetAsync(g_mu, 0, S * p->W * 4, st)) || (e = hipMemsetAsync(g_z, 0, 4, st)) ||
+            (e = hipMemsetAsync(g_cx, 0, (size_t)p->F * 4, st)) || (e = hipMemsetAsync(g_cy, 0, (size_t)p->F * 4, st)) ||
+            (g_kappa && (e = hipMemsetAsync(g_kappa, 0, S * 4, st))) || (g_poly && (e = hipMemsetAsync(g_poly, 0, S * 16, st))))
             return hip_fail(e, "hipMemsetAsync(grads)");
         return TL_OK;
     }
@@ -315,6 +339,18 @@ int tl_spot_moments(int32_t device, int32_t F, int32_t P, int32_t W, const float
                        moments, W, pl.nbx);
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_moments_kernel launch");
+    return TL_OK;
+}
+
+int tl_spot_rms(int32_t device, int32_t F, double n_per_field, const double *moments, float *rms, double *d_moments,
+                void *stream)
+{
+    if (F < 1 || !(n_per_field > 0.0) || !moments || !rms || !d_moments) return fail(TL_EINVAL, "tl_spot_rms: bad argument");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    hipLaunchKernelGGL(spot_rms_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, moments, F, n_per_field, rms, d_moments);
+    const int herr = (int)hipGetLastError();
+    if (herr) return hip_fail(herr, "spot_rms_kernel launch");
     return TL_OK;
 }
 

@@ -191,27 +191,53 @@ class TraceFunction(torch.autograd.Function):
         need_xin, need_yin = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gxin = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if need_xin else None
         gyin = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if need_yin else None
-        sizes = [S, S, W * S, 1, F, F] + ([S, 4 * S] if asph else [])
-        gpar = torch.empty(sum(sizes), dtype=torch.float64, device=dev)
-        parts = torch.split(gpar, sizes)
-        g_kappa, g_poly = (parts[6], parts[7]) if asph else (None, None)
+        # one fp32 tensor per parameter group, written by the reduction kernel (fp64 sums rounded once):
+        # autograd can take them as the leaves' .grad without a cast or a clone
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)     # noqa: E731
+        parts = [new(S), new(S), new(W, S), new(1), new(F), new(F)]
+        g_kappa, g_poly = (new(S), new(S, 4)) if asph else (None, None)
         with torch.cuda.device(dev), _Timed("bwd", dev):
             rc = lib.tl_trace_bwd(C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd),
                                   _lib.ptr(gmd), *[_lib.ptr(q) for q in parts[:6]], _lib.ptr(g_kappa), _lib.ptr(g_poly),
                                   _lib.ptr(gxin), _lib.ptr(gyin), _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
         _lib.check(rc, "tl_trace_bwd")
-        parts = torch.split(gpar.to(torch.float32), sizes)
-        g_c, g_t, g_mu, g_z, g_cx, g_cy = parts[:6]
-        if cx.numel() == 1:
+        g_c, g_t, g_mu, g_z, g_cx, g_cy = parts
+        need = ctx.needs_input_grad
+        if need[3] and cx.numel() == 1:
             g_cx = g_cx.sum(dim=0, keepdim=True)
-        if cy.numel() == 1:
+        if need[4] and cy.numel() == 1:
             g_cy = g_cy.sum(dim=0, keepdim=True)
         return (gxin.permute(0, 1, 3, 2) if need_xin else None,
                 gyin.permute(0, 1, 3, 2) if need_yin else None,
-                g_z.reshape(z.shape), g_cx.reshape(cx.shape), g_cy.reshape(cy.shape),
+                g_z.reshape(z.shape) if need[2] else None, g_cx.reshape(cx.shape) if need[3] else None,
+                g_cy.reshape(cy.shape) if need[4] else None,
                 g_c.reshape(c.shape), g_t.reshape(t.shape), g_mu.reshape(mu.shape),
-                parts[6].reshape(kappa.shape) if asph else None, parts[7].reshape(poly.shape) if asph else None,
+                g_kappa.reshape(kappa.shape) if asph else None, g_poly.reshape(poly.shape) if asph else None,
                 None, None, None, None, None, None, None, None, None)
+
+
+class SpotRmsFunction(torch.autograd.Function):
+    """rms = compute_rms2d on the [F, TL_NMOM] moments (closed form) with its derivative, one tiny
+    kernel each way instead of the ~25 elementwise kernels of the eager formula and its autograd."""
+
+    @staticmethod
+    def forward(ctx, moments, n_per_field):
+        _require_device(moments, "moments")
+        dev = moments.device
+        m = moments.to(torch.float64).contiguous()
+        rms = torch.empty((), dtype=torch.float32, device=dev)
+        dm = torch.empty_like(m)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().tl_spot_rms(dev.index, m.shape[0], float(n_per_field), _lib.ptr(m), _lib.ptr(rms),
+                                        _lib.ptr(dm), _stream_ptr(dev))
+        _lib.check(rc, "tl_spot_rms")
+        ctx.save_for_backward(dm)
+        return rms
+
+    @staticmethod
+    def backward(ctx, g):
+        (dm,) = ctx.saved_tensors
+        return dm * g.to(torch.float64), None
 
 
 class SpotMomentsFunction(torch.autograd.Function):

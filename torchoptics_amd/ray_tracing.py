@@ -213,8 +213,9 @@ def compute_rms2d(x, y, ray_ok, group=None, n_per_field: Optional[int] = None):
         moments = tl_dist.all_reduce_sum(moments, group)
         if n_per_field is None:
             n_per_field = n_local * torch.distributed.get_world_size(group)
-    rms = rms_from_moments(moments, n_per_field or n_local)
-    return rms.to(y.dtype)
+    if moments.is_cuda:
+        return ops.SpotRmsFunction.apply(moments, n_per_field or n_local).to(y.dtype)
+    return rms_from_moments(moments, n_per_field or n_local).to(y.dtype)
 
 
 # ---------------------------------------------------------------------------- RayTracer
