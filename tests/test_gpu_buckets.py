@@ -139,3 +139,33 @@ def test_two_host_threads_share_the_library(ta):
     assert not errors, errors
     for got, w in zip(results, want):
         assert all(torch.equal(g_, w_) for g_, w_ in zip(got, w))
+
+
+def test_plain_cpp_host_on_the_c_abi_matches_python_path(ta):
+    """examples/cabi_demo.bin (C++ only: hipMalloc + the tl_* entry points) traces the singlet and
+    back-propagates the RMS spot; the Python path on the same fan must give the same numbers."""
+    import json
+    import os
+    import subprocess
+    import yaml_free_lenses as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "cabi_demo.bin")
+    if not os.path.exists(exe):
+        from torchoptics_amd.build import build_cabi_demo
+        build_cabi_demo(verbose=False)
+    out = subprocess.run([exe, "64", "64"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    demo = json.loads(out.stdout.strip().splitlines()[-1])
+    lens, specs, leaves = L.build("singlet", DEV)
+    tr = ta.RayTracer(mode="circular", n_rays=(64, 64), rel_fields=(0.,), wavelengths=("d",), default_device=DEV)
+    a = tr.assemble(specs, lens)
+    lv = {k: a[k].detach().clone().requires_grad_(True) for k in ("c", "t", "mu")}
+    x, y, cx, cy, ok, back = ta.trace_skew(a["x"], a["y"], a["z"], a["cx"], a["cy"], lv["c"], lv["t"], lv["mu"], a["mask"])
+    rms = ta.compute_rms2d(x, y, ok)
+    rms.backward()
+    assert demo["rays"] == 4096 and demo["ok"] == float(ok.sum().item())
+    # the C++ host builds the pupil grid with its own cosf/sinf: equal to ~1e-6 relative, not bit-equal
+    assert abs(demo["rms"] - rms.item()) <= 2e-5 * rms.item()
+    for k in ("c", "t", "mu"):
+        got = np.array(demo["g_" + k])
+        assert rel_l2(got, lv[k].grad.cpu().numpy().ravel()) <= 1e-4, k

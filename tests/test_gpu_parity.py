@@ -219,3 +219,22 @@ def test_cfg2_full_size_scalars(ta):
         print(f"cfg2 d/d{k}: vs fp32 autograd {e32:.2e}, vs fp64 autograd {e64:.2e}, "
               f"fp32-vs-fp64 of the reference {rel_l2(g['g_' + k], g['g_' + k + '64']):.2e}")
         assert e64 < 5e-5, f"d/d{k} vs fp64: {e64:.2e}"
+
+
+def test_two_dimensional_rms_extension(ta):
+    """compute_rms_spot_xy (x- and y-moments from the kernel) vs the same statistic formed with plain
+    torch ops on the per-ray outputs, and its gradient vs autograd through the dense-gradient path."""
+    from torchoptics_amd import ray_tracing as rt
+    g = load_golden("G5_cooke_failures")
+    ins, mask, allow = dev_inputs(g, grad=True)
+    x, y, cx, cy, ok, back = ta.trace_skew(*ins, mask, False, allow)
+    got = rt.compute_rms_spot_xy(x, y, ok)
+    n = y.shape[2] * y.shape[3]
+    okd, xd, yd = ok[0].double(), x[0].double(), y[0].double()
+    mx, my = xd.sum(dim=(1, 2), keepdim=True) / n, yd.sum(dim=(1, 2), keepdim=True) / n
+    want = torch.sqrt((okd * ((xd - mx) ** 2 + (yd - my) ** 2)).sum(dim=(1, 2)) / n).mean()
+    assert abs(got.item() - want.item()) <= 1e-6 * want.item()
+    ga = torch.autograd.grad(got, ins[5:], retain_graph=True)
+    gb = torch.autograd.grad(want, ins[5:])
+    for a, b in zip(ga, gb):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-5

@@ -91,5 +91,21 @@ def _build(OBJ, LIB, extra_flags, force, verbose):
     return LIB
 
 
+def build_cabi_demo(verbose=True):
+    """examples/cabi_demo.bin: a plain C++ host program on the C ABI (no Python, no torch)."""
+    src = os.path.join(ROOT, "examples", "cabi_demo.cpp")
+    out = os.path.join(ROOT, "examples", "cabi_demo.bin")
+    deps = [src, LIB, os.path.join(ROOT, "include", "tl_trace.h")]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O2", "-std=c++17", src, "-I", os.path.join(ROOT, "include"),
+           "-L", HERE, "-ltltrace", "-Wl,-rpath,$ORIGIN/../torchoptics_amd", "-o", out]
+    if verbose:
+        print("[tltrace]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv))
+    print(build_cabi_demo())

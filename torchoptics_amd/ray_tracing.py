@@ -218,6 +218,29 @@ def compute_rms2d(x, y, ray_ok, group=None, n_per_field: Optional[int] = None):
     return rms_from_moments(moments, n_per_field or n_local).to(y.dtype)
 
 
+def compute_rms_spot_xy(x, y, ray_ok, group=None, n_per_field: Optional[int] = None):
+    """Extension (not in the reference, whose compute_rms2d ignores x): mean over fields of the 2-D RMS
+    spot radius sqrt(<(x - x_c)^2 + (y - y_c)^2>) with the same conventions as compute_rms2d (centroid over
+    all rays, failed rays at the origin, denominator P*W).  Uses the x- and y-moments fused into the trace
+    kernel; differentiable through the same backward kernel."""
+    tag = getattr(y, "_tl_spot", None)
+    if tag is not None and tag[1] is ray_ok and tag[2] == y._version:
+        moments, n_local = tag[0], tag[3]
+    else:
+        moments = ops.SpotMomentsFunction.apply(x, y, ray_ok)
+        n_local = y.shape[2] * y.shape[3]
+    if group is not None:
+        from . import dist as tl_dist
+        moments = tl_dist.all_reduce_sum(moments, group)
+        if n_per_field is None:
+            n_per_field = n_local * torch.distributed.get_world_size(group)
+    n = n_per_field or n_local
+    my, mx = moments[:, 0] / n, moments[:, 4] / n
+    var = ((moments[:, 2] - 2 * my * moments[:, 1] + my * my * moments[:, 3])
+           + (moments[:, 6] - 2 * mx * moments[:, 5] + mx * mx * moments[:, 3])) / n
+    return torch.sqrt(var).mean().to(y.dtype)
+
+
 # ---------------------------------------------------------------------------- RayTracer
 class RayTracer:
     """Builds the ray fan for a `Specs`/`Lens` pair and traces it (ray_tracing_lite.py:26-208)."""
