@@ -160,8 +160,6 @@ def test_product_has_no_cpu_path():
 
 
 def test_unsupported_options_raise():
-    with pytest.raises(NotImplementedError):
-        ta.RayTracer(mode="chief")
     with pytest.raises(ValueError):
         ta.RayTracer(mode="bogus")
     with pytest.raises(NotImplementedError):

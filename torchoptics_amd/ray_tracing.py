@@ -23,9 +23,8 @@ from .paraxial import (compute_last_curvature, compute_magnification, compute_pu
                        compute_pupil_radius, get_first_order, interface_propagation_abcd, reduce_abcd)
 
 _LINES = {'C': 656.3, 'd': 587.6, 'F': 486.1}
-_WORKING_MODES = ('skew_random', 'tee', 'circular')
-_UNPORTED_MODES = ('skew_uniform_half_equidistant', 'skew_uniform_half_jittered', 'skew_inner_square_half',
-                   'skew_outer_edge_uniform', 'meridional_uniform', 'sagittal_uniform', 'chief')
+_MODES = ('skew_random', 'tee', 'circular', 'skew_uniform_half_equidistant', 'skew_uniform_half_jittered',
+          'skew_inner_square_half', 'skew_outer_edge_uniform', 'meridional_uniform', 'sagittal_uniform', 'chief')
 
 
 # ---------------------------------------------------------------------------- pupil samplers
@@ -68,6 +67,80 @@ def circle_pseudo_random(tensor, n_r, n_theta):
     th = (d_th + th_0) * 2 * np.pi
     n = n_r * n_theta
     return (r * torch.cos(th)).view(-1, 1, n, 1), (r * torch.sin(th)).view(-1, 1, n, 1)
+
+
+# The remaining sampling modes exist in the reference only as commented-out TensorFlow code
+# (ray_tracing_lite.py:363-480; originals in ray_tracing.py:358-476) and raise NameError in its PyTorch
+# port.  Written here from their stated intent; PARITY UNPINNED (the TF original cannot run here).
+def _as_rays(x, y, device):
+    x = torch.as_tensor(np.asarray(x, dtype=np.float32)).to(device)
+    y = torch.as_tensor(np.asarray(y, dtype=np.float32)).to(device)
+    return x.reshape(1, 1, -1, 1), y.reshape(1, 1, -1, 1)
+
+
+def chief(tensor, _n=None, device="cuda"):
+    """The chief ray: pupil centre."""
+    return _as_rays([0.0], [0.0], device)
+
+
+def meridional_uniform(tensor, n_rays, device="cuda"):
+    """n_rays points on the y axis of the pupil, from -1 to 1 inclusive."""
+    y = np.linspace(-1.0, 1.0, n_rays)
+    return _as_rays(np.zeros_like(y), y, device)
+
+
+def sagittal_uniform(tensor, n_rays, device="cuda"):
+    """n_rays points on the positive x axis of the pupil, from 0 to 1 inclusive."""
+    x = np.linspace(0.0, 1.0, n_rays)
+    return _as_rays(x, np.zeros_like(x), device)
+
+
+def circle_outer_edge_uniform(tensor, n_rays, device="cuda"):
+    """n_rays points on the rim of the pupil, equally spaced in angle starting at +x."""
+    th = np.linspace(0, 2 * np.pi, n_rays, endpoint=False, dtype=np.float32)
+    return _as_rays(np.cos(th), np.sin(th), device)
+
+
+def _half_shells(n_r, n_i):
+    """Shell index of every ray and its polar angle for the right-half-pupil patterns: shell i holds
+    n_i (2 i + 1) rays spread over (-pi/2, pi/2) at the midpoints of equal angular bins (equal area per ray)."""
+    counts = [n_i * (2 * i + 1) for i in range(n_r)]
+    shell = np.repeat(np.arange(n_r), counts)
+    theta = np.concatenate([((np.arange(n) + 0.5) / n - 0.5) * np.pi for n in counts])
+    return shell, theta
+
+
+def skew_uniform_half_equidistant(tensor, n_r, n_i, device="cuda"):
+    """n_i n_r^2 rays over the right half of the pupil; shell i sits at radius (i + 0.5) / n_r."""
+    shell, theta = _half_shells(n_r, n_i)
+    r = (shell + 0.5) / n_r
+    return _as_rays(r * np.cos(theta), r * np.sin(theta), device)
+
+
+def skew_uniform_half_jittered(tensor, n_r, n_i, device="cuda"):
+    """As above, but the rays of a shell alternate between its inner radius and the next half step
+    outwards (radii 0, 1/(2 n_r - 1), 2/(2 n_r - 1), ... 1), so that the pupil edge is sampled."""
+    shell, theta = _half_shells(n_r, n_i)
+    inner = np.linspace(0, 1, 2 * n_r)[::2]
+    step = 1.0 / (2 * n_r - 1)
+    r = inner[shell] + step * ((np.arange(len(shell)) + shell) % 2)
+    return _as_rays(r * np.cos(theta), r * np.sin(theta), device)
+
+
+def skew_inner_square_half(tensor, n_y, _unused=None, device="cuda"):
+    """n_y x n_y grid over the right half of the square inscribed in the pupil."""
+    xs = np.linspace(-1, 1, 2 * n_y)[-n_y:] / np.sqrt(2)
+    ys = np.linspace(-1, 1, n_y) / np.sqrt(2)
+    gx, gy = np.meshgrid(xs, ys)          # rows: y, columns: x
+    return _as_rays(gx.ravel(), gy.ravel(), device)
+
+
+def apply_vignetting(y, vig_up, vig_down):
+    """Squeeze relative pupil coordinates: the upper edge moves in by vig_up, the lower by vig_down."""
+    pad = [1] * (y.dim() - vig_down.dim())
+    vig_up = vig_up.reshape(*vig_up.shape, *pad)
+    vig_down = vig_down.reshape(*vig_down.shape, *pad)
+    return y * (1 - (vig_up + vig_down) / 2) + (vig_down - vig_up) / 2
 
 
 def scale_to_epd(y, epd):
@@ -250,21 +323,27 @@ class RayTracer:
                  ray_aiming_mode='real', allow_backward_rays=True, default_device='cuda', arith=None):
         self.mode = mode
         self.default_device = default_device
-        if mode in ('skew_random', 'circular'):
+        dev = default_device
+        two = lambda fn: (lambda tensor: fn(tensor, *n_rays, device=dev))      # noqa: E731  (n_r, n_theta)-style
+        one = lambda fn: (lambda tensor: fn(tensor, n_rays, device=dev))       # noqa: E731  count-style
+        spans = {
+            'skew_random': lambda tensor: circle_pseudo_random(tensor, *n_rays),
+            'circular': lambda tensor: circle(tensor, *n_rays, dev),
+            'tee': lambda tensor: tee(tensor, dev),
+            'skew_uniform_half_equidistant': two(skew_uniform_half_equidistant),
+            'skew_uniform_half_jittered': two(skew_uniform_half_jittered),
+            'skew_inner_square_half': two(skew_inner_square_half),
+            'skew_outer_edge_uniform': one(circle_outer_edge_uniform),
+            'meridional_uniform': one(meridional_uniform),
+            'sagittal_uniform': one(sagittal_uniform),
+            'chief': one(chief),
+        }
+        if mode not in spans:
+            raise ValueError(f"Ray tracing mode must be one of {_MODES}")        # the reference `assert`s a ValueError (B6)
+        if mode in ('skew_random', 'circular', 'skew_uniform_half_equidistant', 'skew_uniform_half_jittered',
+                    'skew_inner_square_half'):
             assert len(n_rays) == 2
-        if mode == 'skew_random':
-            self.pupil_span = lambda tensor: circle_pseudo_random(tensor, *n_rays)
-        elif mode == 'circular':
-            self.pupil_span = lambda tensor: circle(tensor, *n_rays, self.default_device)
-        elif mode == 'tee':
-            self.pupil_span = lambda tensor: tee(tensor, self.default_device)
-        elif mode in _UNPORTED_MODES:
-            raise NotImplementedError(f"pupil sampling mode '{mode}' has no working definition in the "
-                                      f"reference PyTorch port (it raises NameError there); use one of {_WORKING_MODES}")
-        else:
-            raise ValueError(f"Ray tracing mode must be one of {_WORKING_MODES + _UNPORTED_MODES}")
-        if vig_fn is not None:
-            raise NotImplementedError("vignetting functions are not supported (broken in the reference port too)")
+        self.pupil_span = spans[mode]
         if double_precision:
             raise NotImplementedError("the HIP kernels compute in fp32; double_precision is not available")
         self.n_rays = n_rays
@@ -286,6 +365,8 @@ class RayTracer:
         n = n.reshape(n.shape[0], 1, 1, n.shape[1], -1)                   # [1,1,1,W,S+1]
         z = compute_pupil_position(lens).reshape(-1, 1, 1, 1)
         xp_rel, yp_rel = self.pupil_span(z) if xy is None else xy
+        if use_vig and self.vig_fn is not None and self.mode != 'chief':
+            yp_rel, xp_rel = self._vignette(specs, yp_rel.to(dev), xp_rel.to(dev))
         if self.n_ray_aiming_iter > 0 and not up_to_stop:
             aim = self.ray_aiming(specs, lens.detach(), use_vig)
             xp_rel, yp_rel = (torch.clamp(v, -2, 2).to(dev).detach() for v in aim(xp_rel, yp_rel))
@@ -301,6 +382,13 @@ class RayTracer:
         if getattr(lens, "kappa", None) is not None:        # aspheric extension of Lens (not in the reference)
             out.update(kappa=lens.kappa, poly=lens.poly, n_index=n)
         return out
+
+    def _vignette(self, specs, yp_rel, xp_rel):
+        """Per-field vignetting of the relative pupil coordinates (ray_tracing.py:479-490 of the TF original):
+        `vig_fn(fields [1,F], v [B]) -> [B,F]` interpolates the three vignetting factors over the field."""
+        fields = torch.tensor(self.rel_fields, dtype=torch.float32, device=yp_rel.device)[None, :]
+        up, down, vx = (self.vig_fn(fields, v) for v in (specs.vig_up, specs.vig_down, specs.vig_x))
+        return apply_vignetting(yp_rel, up, down), apply_vignetting(xp_rel, vx, vx)
 
     def trace_rays(self, specs, lens, use_vig=True, aggregate=False, xy=None, up_to_stop=False, want_opd=False):
         a = self.assemble(specs, lens, xy=xy, up_to_stop=up_to_stop, use_vig=use_vig)
@@ -337,6 +425,8 @@ class RayTracer:
         xt0, yt0 = tee(None, self.default_device)
         shape = (len(lens), len(self.rel_fields), xt0.shape[2], len(self.wavelengths))
         xt_ref, yt_ref = xt0.expand(shape).clone(), yt0.expand(shape).clone()
+        if use_vig and self.vig_fn is not None:
+            yt_ref, xt_ref = self._vignette(specs, yt_ref, xt_ref)
         with torch.enable_grad():
             xt = xt_ref.clone().requires_grad_(True)
             yt = yt_ref.clone().requires_grad_(True)
