@@ -114,8 +114,9 @@ def flops_per_ray(S):
     step_fwd 54 per surface (+5 image plane); step_bwd 49 recompute + 99 adjoint per surface; the
     backward kernel runs step_fwd once more to reach the image plane (+30 seeds/entrance)."""
     fwd = 54 * S + 5
-    bwd = fwd + (49 + 99) * S + 30
-    return fwd, bwd
+    bwd = fwd + (49 + 99) * S + 30          # checkpoint kernel: forward sweep + recompute + adjoint
+    bwd_inv = (51 + 17 + 99) * S + 40       # walk-back kernel: inverse refraction + intersection, partial recompute, adjoint
+    return fwd, bwd, bwd_inv
 
 
 def main():
@@ -217,8 +218,14 @@ def main():
 
     # ---- roofline of the dominant kernel (trace_bwd_kernel), per launch, from live event timing
     fw = meta["F"] * meta["W"]
-    b_fwd, b_bwd = 18.0 + 8.0 / fw, 8.0 / fw      # algorithmic bytes per ray (DESIGN.md "bytes per unit")
-    f_fwd, f_bwd = flops_per_ray(meta["S"])     # counted for spherical rows; aspheric rows cost more (not counted)
+    from torchoptics_amd import ops as _ops
+    inv = _ops.get_backward_algorithm() == "inverse" and "kappa" not in args
+    # algorithmic bytes per ray (DESIGN.md "bytes per unit"): forward writes x,y,cx,cy,ok,back and reads x_in,y_in;
+    # the walk-back backward reads x_in,y_in and the forward's x,y,cx,cy,ok; the checkpoint backward only x_in,y_in
+    b_fwd, b_bwd = 18.0 + 8.0 / fw, (17.0 if inv else 0.0) + 8.0 / fw
+    f_fwd, f_ck, f_inv = flops_per_ray(meta["S"])     # counted for spherical rows; aspheric rows cost more (not counted)
+    f_bwd = f_inv if inv else f_ck
+    bwd_kernel_name = "trace_bwd_inv_kernel" if inv else "trace_bwd_kernel"
     kernels = {}
     for key, bpr, fpr in (("fwd", b_fwd, f_fwd), ("bwd", b_bwd, f_bwd)):
         ms = kern_ms.get(key)
@@ -228,7 +235,7 @@ def main():
     dom = kernels.get("bwd")
     roofline = None
     if dom:
-        roofline = dict(kernel="trace_bwd_kernel", bound="hbm", achieved=dom["hbm_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+        roofline = dict(kernel=bwd_kernel_name, bound="hbm", achieved=dom["hbm_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=dom["hbm_GBs"] / HBM_PEAK_GBS, traffic=pmc_traffic(a.workload, a.mode, "bwd", meta),
                         launch_ms=dom["ms"], algorithmic_bytes_per_launch=rays_local * b_bwd,
                         note="per-ray FMA kernel: the binding limit is the FP32 vector ALU, see roofline_valu; "
@@ -236,7 +243,7 @@ def main():
                              "(profiles/r01_pmc_traffic.json), null for workloads not profiled")
     roofline_valu = None
     if dom:
-        roofline_valu = dict(kernel="trace_bwd_kernel", bound="valu_fp32", achieved=dom["valu_TFLOPs"],
+        roofline_valu = dict(kernel=bwd_kernel_name, bound="valu_fp32", achieved=dom["valu_TFLOPs"],
                              peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=dom["valu_TFLOPs"] / VALU_PEAK_TFLOPS)
     # whole-step algorithmic HBM rate (fwd + bwd bytes at the API boundary, SURVEY 8d headline)
     step_bytes = rays_total * (b_fwd + b_bwd)
@@ -299,7 +306,9 @@ def main():
             "config": {"workload": f"{a.workload}: {meta['lens']} S={meta['S']} rows, F={meta['F']} W={meta['W']} "
                                    f"P={meta['P_local']} pupil points per GPU ({rays_local} rays/GPU, {rays_total} total), "
                                    f"circular grid, loss=compute_rms2d, fwd+bwd",
-                       "arith_mode": a.mode, "parallelism": f"pupil-sharded dp{world}", "rms": float(rms.item()),
+                       "arith_mode": a.mode, "backward_algorithm": "walk-back from the forward outputs (checkpoint kernel "
+                       "as on-device fallback for ill-conditioned fans)" if inv else "checkpoint",
+                       "parallelism": f"pupil-sharded dp{world}", "rms": float(rms.item()),
                        "hip_graph": bool(a.graph)},
             "roofline": roofline, "roofline_valu": roofline_valu, "kernels": kernels,
             "step_hbm_GBs": step_bytes / (dt / a.steps) / 1e9,

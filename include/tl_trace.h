@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 6
+#define TL_ABI_VERSION 8
 #define TL_MAX_SURFACES 32       /* rows per lens the backward kernels are built for */
 #define TL_NMOM 10               /* per-field sums, see tl_trace_fwd */
 #define TL_MAX_POLY 4            /* even aspheric terms a4,a6,a8,a10 */
@@ -94,7 +94,9 @@ size_t tl_workspace_bytes(const tl_problem *p);
  *               forward only: no gradient flows through it)
  *   moments   : [F,TL_NMOM] double (nullable), per field over (w,p):
  *               0 sum y | 1 sum ok*y | 2 sum ok*y^2 | 3 sum ok | 4 sum x | 5 sum ok*x |
- *               6 sum ok*x^2 | 7 sum back | 8 sum q (p->aggregate only) | 9 reserved
+ *               6 sum ok*x^2 | 7 sum back | 8 sum q (p->aggregate only) |
+ *               9 number of ILL-CONDITIONED live rays: smallest cos^2 of incidence / refraction along the
+ *                 path below 0.01 (fp32 rounding is amplified ~1/cos^2 there)
  *               -- 0..3 are the sufficient statistics of compute_rms2d (ray_tracing_lite.py:678-702);
  *               q = per-ray sum over the surfaces of theta_norm + theta_prime_norm + z_RELU
  *               (ray_tracing_lite.py:641-657), NaN -> 0, i.e. sumQ * n_sequence of
@@ -128,6 +130,27 @@ int tl_trace_bwd(const tl_problem *p,
                  float *g_kappa, float *g_poly,
                  float *g_x_in, float *g_y_in,
                  void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Backward trace WITHOUT re-tracing forwards: same gradients as tl_trace_bwd, computed by walking each ray
+ * back from the forward kernel's own output (x, y, cx, cy, ok of tl_trace_fwd for this problem) -- undo
+ * the refraction at surface k, intersect the incoming line with surface k-1, apply the adjoint step.
+ * No per-surface state is kept, so the kernel runs at twice the occupancy and needs no bit-exact
+ * re-derivation of the forward; the reconstructed states differ from the forward's by rounding only,
+ * which perturbs the gradients at the 1e-6 level (tested) -- except for ill-conditioned rays (moment 9 of
+ * tl_trace_fwd), where it would reach 1e-4: pass the forward's moments as `moments_fwd` (nullable) and the
+ * call also enqueues the checkpoint kernel of tl_trace_bwd; the two launches read the count ON THE DEVICE
+ * and only one of them does the work (no host synchronisation; the idle launch retires in microseconds).
+ * All-spherical lenses, allow_backward = 1, aggregate = 0 only (TL_EINVAL otherwise: use tl_trace_bwd).
+ */
+int tl_trace_bwd_from_outputs(const tl_problem *p,
+                              const float *gx, const float *gy, const float *gcx, const float *gcy,
+                              const double *g_moments,
+                              const float *x_fwd, const float *y_fwd, const float *cx_fwd, const float *cy_fwd,
+                              const uint8_t *ok_fwd, const double *moments_fwd,
+                              float *g_c, float *g_t, float *g_mu, float *g_z, float *g_cx, float *g_cy,
+                              float *g_x_in, float *g_y_in,
+                              void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Spot moments of arbitrary per-ray tensors (same TL_NMOM layout): the reduction inside

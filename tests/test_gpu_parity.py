@@ -238,3 +238,87 @@ def test_two_dimensional_rms_extension(ta):
     gb = torch.autograd.grad(want, ins[5:])
     for a, b in zip(ga, gb):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("case", [c for c in RAY_CASES if "noback" not in c])
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_checkpoint_free_backward_vs_reference_autograd(ta, case, mode):
+    """tl_trace_bwd_from_outputs (walk back from the forward's outputs, no checkpoints): gradients of the
+    lens parameters vs the reference's autograd, and vs the checkpoint kernel, on every fixture incl. the
+    failure-heavy one.  strict: 1e-5 vs fp32 autograd (or within the fp32 reference's own distance from
+    fp64); fast: 1e-4.  Launch conditions z, cy: 1e-3 (cancellation-heavy)."""
+    from torchoptics_amd import ops
+    g = load_golden(case)
+    res = {}
+    for algo in ("inverse", "checkpoint"):
+        ops.set_backward_algorithm(algo)
+        try:
+            ins, mask, allow = dev_inputs(g)
+            lv = [ins[i].clone().requires_grad_(True) for i in (2, 4, 5, 6, 7)]
+            x, y, cx, cy, ok, back = ta.trace_skew(ins[0], ins[1], lv[0], ins[3], lv[1], lv[2], lv[3], lv[4], mask,
+                                                   False, allow, mode=mode)
+            ctx_inv = x.grad_fn.use_inv if hasattr(x.grad_fn, "use_inv") else None
+            ta.compute_rms2d(x, y, ok).backward()
+            res[algo] = ([q.grad.cpu().numpy() for q in lv], ctx_inv)
+        finally:
+            ops.set_backward_algorithm("inverse")
+    assert res["inverse"][1] is True and res["checkpoint"][1] is False       # each ran the intended kernel
+    tol = 1e-5 if mode == "strict" else 1e-4
+    for n, gi, gc_ in zip(("z", "cy", "c", "t", "mu"), *[res[k][0] for k in ("inverse", "checkpoint")]):
+        w32, w64 = g["gin_" + n], g["gin_" + n + "64"]
+        if np.linalg.norm(w64) < 1e-6 * np.linalg.norm(g["gin_c64"]):     # zero by symmetry (on-axis-only fans)
+            continue
+        e32, e64, noise = rel_l2(gi, w32), rel_l2(gi, w64), rel_l2(w32, w64)
+        lim = tol if n in ("c", "t", "mu") else 1e-3
+        assert e32 <= lim or e64 <= max(lim, 2 * noise), f"{case} {mode} d/d{n}: vs fp32 {e32:.2e}, vs fp64 {e64:.2e}"
+        assert rel_l2(gi, gc_) <= (2e-5 if n in ("c", "t", "mu") else 2e-3), f"{case} {mode} d/d{n}: inverse vs checkpoint"
+
+
+def test_checkpoint_free_backward_with_dense_upstream_gradients(ta):
+    """Arbitrary loss on x, y, cx, cy (dense seeds) through the walk-back kernel vs fp64 oracle autograd."""
+    from oracle import trace_oracle as orc
+    g = load_golden("G4_tessar_32x32")
+    ins, mask, allow = dev_inputs(g)
+    lv = [ins[i].clone().requires_grad_(True) for i in (5, 6, 7)]
+    gen = torch.Generator().manual_seed(3)
+    wts = [torch.randn(g["x"].shape, generator=gen) for _ in range(4)]
+    outs = ta.trace_skew(*ins[:5], *lv, mask, False, allow)
+    assert outs[0].grad_fn.use_inv is True
+    loss = sum((o * w.to(DEV)).sum() for o, w in zip(outs[:4], wts))
+    got = torch.autograd.grad(loss, lv)
+    cpu = [torch.from_numpy(g[n]).double() for n in IN_NAMES]
+    clv = [cpu[i].clone().requires_grad_(True) for i in (5, 6, 7)]
+    ref_outs = orc.trace_skew(*cpu[:5], *clv, torch.from_numpy(g["in_mask"]), False, allow)
+    want = torch.autograd.grad(sum((o * w.double()).sum() for o, w in zip(ref_outs[:4], wts)), clv)
+    for n, a, b in zip(("c", "t", "mu"), got, want):
+        assert rel_l2(a.cpu().numpy(), b.numpy()) < 2e-5, n
+
+
+def test_conditioning_count_selects_the_backward_kernel_on_the_device(ta):
+    """Moment 9 = number of live rays with min cos^2 < 0.01 along their path.  Zero for every sane fan (the
+    walk-back kernel then does the backward); non-zero for the failure-heavy fixture, where the checkpoint
+    kernel takes over inside the same call, so that gradients stay within 1e-5 of autograd there too."""
+    counts = {}
+    for case in ("G2_cooke_16x16", "G4_tessar_32x32", "G5_cooke_failures"):
+        g = load_golden(case)
+        ins, mask, allow = dev_inputs(g)
+        x, y, cx, cy, ok, back = ta.trace_skew(*ins, mask, False, allow)
+        counts[case] = y._tl_spot[0][:, 9].sum().item()
+    assert counts["G2_cooke_16x16"] == 0 and counts["G4_tessar_32x32"] == 0
+    assert counts["G5_cooke_failures"] > 0
+    # and the fallback really is bit-identical to calling the checkpoint algorithm directly
+    from torchoptics_amd import ops
+    g = load_golden("G5_cooke_failures")
+    grads = {}
+    for algo in ("inverse", "checkpoint"):
+        ops.set_backward_algorithm(algo)
+        try:
+            ins, mask, allow = dev_inputs(g)
+            lv = [ins[i].clone().requires_grad_(True) for i in (5, 6, 7)]
+            x, y, cx, cy, ok, back = ta.trace_skew(*ins[:5], *lv, mask, False, allow)
+            ta.compute_rms2d(x, y, ok).backward()
+            grads[algo] = [q.grad.clone() for q in lv]
+        finally:
+            ops.set_backward_algorithm("inverse")
+    for a, b in zip(grads["inverse"], grads["checkpoint"]):
+        assert torch.equal(a, b)

@@ -56,6 +56,8 @@ def main():
         dll.tl_version.restype = C.c_int
         ver = dll.tl_version()
         for fn, (res, argt) in _lib._SIGNATURES.items():
+            if not hasattr(dll, fn):                   # older build: entry point not there yet
+                continue
             f = getattr(dll, fn)
             f.restype = res
             if fn == "tl_trace_fwd" and ver < 5:       # older ABI: no `stacks` argument
@@ -76,11 +78,19 @@ def main():
                               P_(g_cx), P_(g_cy), None, None, None, None, P_(ws), ws.numel(), st)
         assert rc == 0, dll.tl_last_error()
 
-    res = {n: {"fwd": [], "bwd": []} for n in libs}
+    def bwd_inv(dll):
+        rc = dll.tl_trace_bwd_from_outputs(C.byref(prob), None, None, None, None, P_(gmom), P_(outs[0]), P_(outs[1]),
+                                           P_(outs[2]), P_(outs[3]), P_(flags[0]), P_(mom), P_(g_c), P_(g_t), P_(g_mu),
+                                           P_(g_z), P_(g_cx), P_(g_cy), None, None, P_(ws), ws.numel(), st)
+        assert rc == 0, dll.tl_last_error()
+
+    res = {n: {"fwd": [], "bwd": [], "bwd_inv": []} for n in libs}
     ref = {}
     for rnd in range(a.rounds + 1):
         for name, dll in libs.items():
-            for key, fn in (("fwd", fwd), ("bwd", bwd)):
+            for key, fn in (("fwd", fwd), ("bwd", bwd), ("bwd_inv", bwd_inv)):
+                if key == "bwd_inv" and (dll._ver < 8 or a.workload == "cfg3a"):
+                    continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 fn(dll)
@@ -100,6 +110,8 @@ def main():
         print(f"  {name:14s} fwd med {statistics.median(r['fwd']):.4f} min {min(r['fwd']):.4f} ms | "
               f"bwd med {statistics.median(r['bwd']):.4f} min {min(r['bwd']):.4f} ms | "
               f"fwd+bwd {rays / (statistics.median(r['fwd']) + statistics.median(r['bwd'])) / 1e6:.2f} G rays/s | "
+              + (f"walk-back bwd med {statistics.median(r['bwd_inv']):.4f} ms -> "
+                 f"{rays / (statistics.median(r['fwd']) + statistics.median(r['bwd_inv'])) / 1e6:.2f} G rays/s | " if r['bwd_inv'] else "") +
               f"d(moments) {dm:.1e} d(grads) {dg:.1e} vs {base}")
 
 

@@ -119,9 +119,18 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
                                                             float *__restrict__ g_t, float *__restrict__ g_mu,
                                                             float *__restrict__ g_z, float *__restrict__ g_cx,
                                                             float *__restrict__ g_cy, int ncol,
-                                                            float *__restrict__ g_kappa, float *__restrict__ g_poly)
+                                                            float *__restrict__ g_kappa, float *__restrict__ g_poly,
+                                                            const double *__restrict__ alt_part, int alt_NS,
+                                                            const double *__restrict__ fmom)
 {
     __shared__ double sm[kBlock];
+    // two candidate partial arrays (walk-back kernel / checkpoint fallback): the forward's conditioning count
+    // says which of the two launches did the work
+    if (alt_part && fmom) {
+        double n = 0.0;
+        for (int f = 0; f < F; ++f) n += fmom[(size_t)f * TL_NMOM + 9];
+        if (n > 0.0) { part = alt_part; NS = alt_NS; ncol = 3 * alt_NS + 3; }
+    }
     int b = blockIdx.x;
     float *out;
     int col, f0 = 0, nf = F, w0 = 0, nw = W;
@@ -238,7 +247,8 @@ size_t tl_workspace_bytes(const tl_problem *p)
     const size_t fw = (size_t)p->F * p->W;
     const size_t a = fw * pf.nbx * TL_NMOM * sizeof(double);
     const size_t b = fw * pb.nbx * (size_t)tl_bwd_row(ns < 0 ? TL_MAX_SURFACES : ns, p->surf_kind != nullptr) * sizeof(double);
-    return (a > b ? a : b) + 256;
+    const size_t c = fw * pb.nbx * (size_t)(3 * p->S + 3) * sizeof(double);   // walk-back kernel next to its fallback
+    return (a > b + c ? a : b + c) + 256;
 }
 
 int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, uint8_t *ok, uint8_t *back,
@@ -313,7 +323,48 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
     if (herr) return hip_fail(herr, "trace_bwd_kernel launch");
     const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0);
     hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout), dim3(kBlock), 0, st, part, ns, p->F, p->W, p->S, pl.nbx, g_c,
-                       g_t, g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly);
+                       g_t, g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly, (const double *)nullptr, 0,
+                       (const double *)nullptr);
+    herr = (int)hipGetLastError();
+    if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");
+    return TL_OK;
+}
+
+int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float *gy, const float *gcx, const float *gcy,
+                              const double *g_moments, const float *x_fwd, const float *y_fwd, const float *cx_fwd,
+                              const float *cy_fwd, const uint8_t *ok_fwd, const double *moments_fwd, float *g_c,
+                              float *g_t, float *g_mu,
+                              float *g_z, float *g_cx, float *g_cy, float *g_x_in, float *g_y_in, void *workspace,
+                              size_t workspace_bytes, void *stream)
+{
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (!g_c || !g_t || !g_mu || !g_z || !g_cx || !g_cy) return fail(TL_EINVAL, "a parameter-gradient output is NULL");
+    if (!x_fwd || !y_fwd || !cx_fwd || !cy_fwd || !ok_fwd) return fail(TL_EINVAL, "the forward outputs x, y, cx, cy, ok are required");
+    if (p->surf_kind || p->aggregate || !p->allow_backward)
+        return fail(TL_EINVAL, "tl_trace_bwd_from_outputs: all-spherical lenses with allow_backward_rays and no penalty term only");
+    if (p->P == 0) return tl_trace_bwd(p, gx, gy, gcx, gcy, g_moments, g_c, g_t, g_mu, g_z, g_cx, g_cy, nullptr, nullptr,
+                                       g_x_in, g_y_in, workspace, workspace_bytes, stream);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSetDevice(p->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    const Plan pl = plan_bwd(p);
+    const int ncol = 3 * p->S + 3, ns = tl_bwd_bucket(p->S), ncol_ck = tl_bwd_row(ns, false);
+    const size_t rows = (size_t)p->F * p->W * pl.nbx;
+    const size_t need_inv = rows * ncol * sizeof(double), need_ck = moments_fwd ? rows * ncol_ck * sizeof(double) : 0;
+    if (!workspace || workspace_bytes < need_inv + need_ck)
+        return fail(TL_EWORKSPACE, "workspace too small for tl_trace_bwd_from_outputs");
+    double *part = (double *)workspace, *part_ck = moments_fwd ? part + rows * ncol : nullptr;
+    int herr = (p->mode == TL_MODE_FAST)
+                   ? tl_fast::api_bwd_inv(*p, gx, gy, gcx, gcy, g_moments, x_fwd, y_fwd, cx_fwd, cy_fwd, ok_fwd,
+                                          moments_fwd, g_x_in, g_y_in, part, part_ck, pl.nbx, pl.R, st)
+                   : tl_strict::api_bwd_inv(*p, gx, gy, gcx, gcy, g_moments, x_fwd, y_fwd, cx_fwd, cy_fwd, ok_fwd,
+                                            moments_fwd, g_x_in, g_y_in, part, part_ck, pl.nbx, pl.R, st);
+    if (herr) return hip_fail(herr, "trace_bwd_inv_kernel launch");
+    const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F;
+    hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout), dim3(kBlock), 0, st, part, p->S, p->F, p->W, p->S, pl.nbx, g_c, g_t,
+                       g_mu, g_z, g_cx, g_cy, ncol, (float *)nullptr, (float *)nullptr, (const double *)part_ck, ns,
+                       moments_fwd);
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");
     return TL_OK;

@@ -19,6 +19,21 @@ from ._lib import TL_NMOM, tl_problem
 
 _MODES = {"strict": _lib.MODE_STRICT, "fast": _lib.MODE_FAST}
 _default_mode = os.environ.get("TORCHOPTICS_AMD_MODE", "strict")
+# backward algorithm: "checkpoint" = re-trace forwards keeping the per-surface states in registers;
+# "inverse" = walk back from the forward kernel's outputs (tl_trace_bwd_from_outputs), used whenever the
+# problem allows it (all-spherical, allow_backward_rays, no penalty term, per-ray outputs were produced)
+_bwd_algo = os.environ.get("TORCHOPTICS_AMD_BWD", "inverse")
+
+
+def set_backward_algorithm(name: str) -> None:
+    global _bwd_algo
+    if name not in ("checkpoint", "inverse"):
+        raise ValueError("backward algorithm must be 'checkpoint' or 'inverse'")
+    _bwd_algo = name
+
+
+def get_backward_algorithm() -> str:
+    return _bwd_algo
 
 
 def set_default_mode(mode: str) -> None:
@@ -153,8 +168,13 @@ class TraceFunction(torch.autograd.Function):
                                   _lib.ptr(opd), _lib.ptr(stacks), _lib.ptr(moments), _lib.ptr(ws), ws.numel(),
                                   _stream_ptr(dev))
         _lib.check(rc, "tl_trace_fwd")
-        ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8)
-        ctx.allow_back, ctx.mode, ctx.aggregate = allow_back, mode, aggregate
+        # per-ray input gradients (ray aiming: a handful of rays) keep the checkpoint algorithm: extreme rays
+        # amplify the reconstruction rounding of the walk-back to ~1e-4 in d/dx_in, d/dy_in
+        use_inv = (_bwd_algo == "inverse" and want_rays and kind_u8 is None and not aggregate and allow_back
+                   and not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
+        fwd_out = (fp[0], fp[1], fp[2], fp[3], bp[0], moments) if use_inv else (None,) * 6
+        ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, *fwd_out)
+        ctx.allow_back, ctx.mode, ctx.aggregate, ctx.use_inv = allow_back, mode, aggregate, use_inv
         ctx.set_materialize_grads(False)
         if want_rays:
             outs = [b.permute(0, 1, 3, 2) for b in fp]
@@ -169,7 +189,7 @@ class TraceFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gx, gy, gcx, gcy, _gok, _gback, gmom, _gopd, _gstk):
-        x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8 = ctx.saved_tensors
+        x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, fx, fy, fcx, fcy, fok, fmom = ctx.saved_tensors
         dev = x_e.device
         F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
         S = c.numel()
@@ -197,9 +217,17 @@ class TraceFunction(torch.autograd.Function):
         parts = [new(S), new(S), new(W, S), new(1), new(F), new(F)]
         g_kappa, g_poly = (new(S), new(S, 4)) if asph else (None, None)
         with torch.cuda.device(dev), _Timed("bwd", dev):
-            rc = lib.tl_trace_bwd(C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd),
-                                  _lib.ptr(gmd), *[_lib.ptr(q) for q in parts[:6]], _lib.ptr(g_kappa), _lib.ptr(g_poly),
-                                  _lib.ptr(gxin), _lib.ptr(gyin), _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
+            if ctx.use_inv:
+                rc = lib.tl_trace_bwd_from_outputs(
+                    C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd), _lib.ptr(gmd),
+                    _lib.ptr(fx), _lib.ptr(fy), _lib.ptr(fcx), _lib.ptr(fcy), _lib.ptr(fok), _lib.ptr(fmom),
+                    *[_lib.ptr(q) for q in parts[:6]], _lib.ptr(gxin), _lib.ptr(gyin), _lib.ptr(ws), ws.numel(),
+                    _stream_ptr(dev))
+            else:
+                rc = lib.tl_trace_bwd(C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd),
+                                      _lib.ptr(gmd), *[_lib.ptr(q) for q in parts[:6]], _lib.ptr(g_kappa),
+                                      _lib.ptr(g_poly), _lib.ptr(gxin), _lib.ptr(gyin), _lib.ptr(ws), ws.numel(),
+                                      _stream_ptr(dev))
         _lib.check(rc, "tl_trace_bwd")
         g_c, g_t, g_mu, g_z, g_cx, g_cy = parts
         need = ctx.needs_input_grad
