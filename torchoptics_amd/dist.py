@@ -5,7 +5,7 @@ Rays never interact inside the trace; the only coupling is the per-field spot st
 So every rank traces its own contiguous slice of the pupil grid and the job needs exactly
 two tiny exchanges per step:
 
-  #1 forward : sum the [F, 8] fp64 spot moments          (all_reduce_sum, differentiable)
+  #1 forward : sum the [F, 10] fp64 spot moments          (all_reduce_sum, differentiable)
   #2 backward: sum the parameter gradients of the leaves (all_reduce_grads)
 
 Both messages are < 2 KB, i.e. latency-bound: one collective each, launched on the compute

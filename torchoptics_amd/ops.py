@@ -269,7 +269,7 @@ class SpotRmsFunction(torch.autograd.Function):
 
 
 class SpotMomentsFunction(torch.autograd.Function):
-    """moments[F, 8] of arbitrary per-ray tensors x, y, ok shaped [1, F, P, W]."""
+    """moments[F, TL_NMOM] of arbitrary per-ray tensors x, y, ok shaped [1, F, P, W]."""
 
     @staticmethod
     def forward(ctx, x, y, ok):
