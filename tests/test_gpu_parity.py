@@ -322,3 +322,32 @@ def test_conditioning_count_selects_the_backward_kernel_on_the_device(ta):
             ops.set_backward_algorithm("inverse")
     for a, b in zip(grads["inverse"], grads["checkpoint"]):
         assert torch.equal(a, b)
+
+
+def test_walk_back_non_finite_adjoint_falls_back_to_checkpoint_kernel(ta):
+    """The walk-back kernel carries no per-surface mask: a non-finite adjoint (which a well-conditioned kept
+    ray cannot produce) raises the poison word in the workspace instead, and the checkpoint kernel queued
+    behind it redoes the launch from the inputs.  Provoked here by corrupting the saved forward outputs of
+    one live ray between forward and backward: the gradients must be bit-equal to the checkpoint algorithm's."""
+    from torchoptics_amd import ops
+    g = load_golden("G4_tessar_32x32")
+    grads = {}
+    for algo in ("inverse", "checkpoint"):
+        ops.set_backward_algorithm(algo)
+        try:
+            ins, mask, allow = dev_inputs(g)
+            lv = [ins[i].clone().requires_grad_(True) for i in (5, 6, 7)]
+            x, y, cx, cy, ok, back = ta.trace_skew(*ins[:5], *lv, mask, False, allow)
+            assert x.grad_fn.use_inv is (algo == "inverse")
+            loss = ta.compute_rms2d(x, y, ok)                  # from the fused moments: untouched by the corruption
+            if algo == "inverse":
+                buf = x.data.permute(0, 1, 3, 2)               # x is a permuted view of the [1,F,W,P] buffer
+                assert buf.is_contiguous()                     # ... which the backward will read
+                live = torch.nonzero(ok.permute(0, 1, 3, 2).reshape(-1))[7]
+                buf.view(-1)[live] = float("nan")
+            loss.backward()
+            grads[algo] = [q.grad.clone() for q in lv]
+        finally:
+            ops.set_backward_algorithm("inverse")
+    for a, b in zip(grads["inverse"], grads["checkpoint"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)

@@ -47,7 +47,7 @@ def main():
     gmom = torch.randn((F, _lib.TL_NMOM), dtype=torch.float64, device=dev) * 1e-3
     gpar = torch.empty(2 * S + W * S + 1 + 2 * F, dtype=torch.float64, device=dev)   # big enough for either ABI
     g_c, g_t, g_mu, g_z, g_cx, g_cy = torch.split(gpar, [S, S, W * S, 1, F, F])
-    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     libs = {}
     for spec in a.libs:

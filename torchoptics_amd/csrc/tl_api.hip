@@ -1,5 +1,6 @@
 // tl_api.hip -- the C ABI of libtltrace.so (declared in include/tl_trace.h): argument
 // checks, launch planning, the fixed-order reduction kernels and the spot kernels.
+#include <atomic>
 #include "tl_common.h"
 
 #include <stdio.h>
@@ -121,15 +122,19 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
                                                             float *__restrict__ g_cy, int ncol,
                                                             float *__restrict__ g_kappa, float *__restrict__ g_poly,
                                                             const double *__restrict__ alt_part, int alt_NS,
-                                                            const double *__restrict__ fmom, int alt_nbx)
+                                                            const double *__restrict__ fmom,
+                                                            const unsigned *__restrict__ poison,
+                                                            unsigned token, int alt_nbx)
 {
     __shared__ double sm[kBlock];
     // two candidate partial arrays (walk-back kernel / checkpoint fallback): the forward's conditioning count
-    // says which of the two launches did the work
-    if (alt_part && fmom) {
+    // and the walk-back's poison word (== this call's token) say which of the two launches did the work (same rule as
+    // fallback_needed in tl_kernels.inc)
+    if (alt_part) {
         double n = 0.0;
-        for (int f = 0; f < F; ++f) n += fmom[(size_t)f * TL_NMOM + 9];
-        if (n > 0.0) { part = alt_part; NS = alt_NS; ncol = 3 * alt_NS + 3; nbx = alt_nbx; }
+        if (fmom)
+            for (int f = 0; f < F; ++f) n += fmom[(size_t)f * TL_NMOM + 9];
+        if (n > 0.0 || (poison && *poison == token)) { part = alt_part; NS = alt_NS; ncol = 3 * alt_NS + 3; nbx = alt_nbx; }
     }
     int b = blockIdx.x;
     float *out;
@@ -324,7 +329,7 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
     const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0);
     hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout), dim3(kBlock), 0, st, part, ns, p->F, p->W, p->S, pl.nbx, g_c,
                        g_t, g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly, (const double *)nullptr, 0,
-                       (const double *)nullptr, 0);
+                       (const double *)nullptr, (const unsigned *)nullptr, 0u, 0);
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");
     return TL_OK;
@@ -353,20 +358,24 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     const Plan pk = make_plan(p->P, p->F * p->W, 1024, 256);
     const int ncol = 3 * p->S + 3, ns = tl_bwd_bucket(p->S), ncol_ck = tl_bwd_row(ns, false);
     const size_t rows = (size_t)p->F * p->W * pl.nbx, rows_ck = (size_t)p->F * p->W * pk.nbx;
-    const size_t need_inv = rows * ncol * sizeof(double), need_ck = moments_fwd ? rows_ck * ncol_ck * sizeof(double) : 0;
-    if (!workspace || workspace_bytes < need_inv + need_ck)
+    const size_t need_inv = rows * ncol * sizeof(double), need_ck = rows_ck * ncol_ck * sizeof(double);
+    if (!workspace || workspace_bytes < need_inv + need_ck + sizeof(double))
         return fail(TL_EWORKSPACE, "workspace too small for tl_trace_bwd_from_outputs");
-    double *part = (double *)workspace, *part_ck = moments_fwd ? part + rows * ncol : nullptr;
+    double *part = (double *)workspace, *part_ck = part + rows * ncol;
+    unsigned *poison = (unsigned *)(part_ck + rows_ck * ncol_ck);      // the walk-back writes `token` here on a non-finite adjoint
+    static std::atomic<uint32_t> calls{0};
+    uint32_t token = (calls.fetch_add(1u) + 1u) * 0x9E3779B1u;         // unique per call, nothing like stale data
+    if (token == 0u) token = 1u;
     int herr = (p->mode == TL_MODE_FAST)
                    ? tl_fast::api_bwd_inv(*p, gx, gy, gcx, gcy, g_moments, x_fwd, y_fwd, cx_fwd, cy_fwd, ok_fwd,
-                                          moments_fwd, g_x_in, g_y_in, part, part_ck, pl.nbx, pl.R, pk.nbx, pk.R, st)
+                                          moments_fwd, g_x_in, g_y_in, part, part_ck, poison, token, pl.nbx, pl.R, pk.nbx, pk.R, st)
                    : tl_strict::api_bwd_inv(*p, gx, gy, gcx, gcy, g_moments, x_fwd, y_fwd, cx_fwd, cy_fwd, ok_fwd,
-                                            moments_fwd, g_x_in, g_y_in, part, part_ck, pl.nbx, pl.R, pk.nbx, pk.R, st);
+                                            moments_fwd, g_x_in, g_y_in, part, part_ck, poison, token, pl.nbx, pl.R, pk.nbx, pk.R, st);
     if (herr) return hip_fail(herr, "trace_bwd_inv_kernel launch");
     const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F;
     hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout), dim3(kBlock), 0, st, part, p->S, p->F, p->W, p->S, pl.nbx, g_c, g_t,
                        g_mu, g_z, g_cx, g_cy, ncol, (float *)nullptr, (float *)nullptr, (const double *)part_ck, ns,
-                       moments_fwd, pk.nbx);
+                       moments_fwd, (const unsigned *)poison, token, pk.nbx);
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");
     return TL_OK;

@@ -27,8 +27,8 @@ static inline int tl_bwd_row(int ns, bool asph) { return (asph ? 8 : 3) * ns + 3
     int api_bwd_inv(const tl_problem &p, const float *gx, const float *gy, const float *gcx,          \
                     const float *gcy, const double *gmom, const float *fx, const float *fy,           \
                     const float *fcx, const float *fcy, const uint8_t *fok, const double *fmom,       \
-                    float *gxin, float *gyin, double *part_inv, double *part_ck, int nbx, int R,      \
-                    int nbx_ck, int R_ck, hipStream_t st);                                           \
+                    float *gxin, float *gyin, double *part_inv, double *part_ck, unsigned *poison,    \
+                    unsigned token, int nbx, int R, int nbx_ck, int R_ck, hipStream_t st);           \
     }
 TL_DECLARE_MODE(tl_strict)
 TL_DECLARE_MODE(tl_fast)

@@ -15,6 +15,6 @@ int api_bwd(const tl_problem &p, const float *gx, const float *gy, const float *
 int api_bwd_inv(const tl_problem &p, const float *gx, const float *gy, const float *gcx, const float *gcy,
                 const double *gmom, const float *fx, const float *fy, const float *fcx, const float *fcy,
                 const uint8_t *fok, const double *fmom, float *gxin, float *gyin, double *part_inv, double *part_ck,
-                int nbx, int R, int nbx_ck, int R_ck, hipStream_t st)
-{ return tl_strict_impl::launch_bwd_inv(p, gx, gy, gcx, gcy, gmom, fx, fy, fcx, fcy, fok, fmom, gxin, gyin, part_inv, part_ck, nbx, R, nbx_ck, R_ck, st); }
+                unsigned *poison, unsigned token, int nbx, int R, int nbx_ck, int R_ck, hipStream_t st)
+{ return tl_strict_impl::launch_bwd_inv(p, gx, gy, gcx, gcy, gmom, fx, fy, fcx, fcy, fok, fmom, gxin, gyin, part_inv, part_ck, poison, token, nbx, R, nbx_ck, R_ck, st); }
 }
