@@ -23,7 +23,12 @@ ARCH = "gfx950"
 #   which on CDNA4 issue no faster than two scalar ops but need 64-bit-aligned register pairs
 #   (hundreds of extra v_mov, +49 VGPRs in the backward kernel): measured -11 % kernel time without it.
 COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-          "-fno-slp-vectorize"]
+          "-fno-slp-vectorize",
+          # The fully unrolled backward kernels hold hundreds of LDS/global stores.  With LLVM's default
+          # MemorySSA walk limit (100) the AMDGPU back end gives up proving that the wave-uniform loads of
+          # the prescription (c, t, mu, kappa, poly) are never clobbered and emits them as VECTOR loads
+          # (180 global_load per ray in trace_bwd_kernel<12,asph>) instead of scalar s_load.
+          "-mllvm", "-memssa-check-limit=4000"]
 # strict: no FMA contraction, HIP's default correctly rounded fp32 sqrt / divide
 # fast  : contraction on; the kernels call v_rcp / v_sqrt explicitly
 UNITS = {
