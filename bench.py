@@ -402,11 +402,40 @@ def cpu_leg(args, meta, log2_rays, mode):
                            "CPU (MKL) is up to 1 ulp off; 'ieee_sqrt' is the same autograd graph with a correctly "
                            "rounded sqrt. pytorch_fp32_self_noise = how far those two PyTorch runs are from each "
                            "other: the floor below which 'vs PyTorch autograd' is not defined for this lens")
+    # SURVEY 8(d), optional extra line: the same eager graph (oracle, ~86 elementwise launches per surface +
+    # autograd) on the MI355X itself, i.e. fused kernels vs eager PyTorch on identical silicon
+    eager_gpu = None
+    if not is_asph:
+        try:
+            pg = max(1, min(meta["P_local"], (1 << 22) // fw))      # 4 M rays: past the launch-bound regime,
+            gsrc = {k: (v.detach().to(dev)) for k, v in cpu.items()}     # ~13 GB of autograd-saved tensors at 11 rows
+            gsrc["x"], gsrc["y"] = args["x"][:, :, :pg].detach().contiguous(), args["y"][:, :, :pg].detach().contiguous()
+            glv = [gsrc[k].requires_grad_(True) for k in names]
+
+            def one_gpu():
+                for q in glv:
+                    q.grad = None
+                o = orc.trace_skew(gsrc["x"], gsrc["y"], gsrc["z"], gsrc["cx"], gsrc["cy"], gsrc["c"], gsrc["t"],
+                                   gsrc["mu"], gsrc["mask"])
+                orc.compute_rms2d(o[0], o[1], o[4]).backward()
+                torch.cuda.synchronize()
+            one_gpu()
+            tg = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                one_gpu()
+                tg.append(time.perf_counter() - t0)
+            eager_gpu = dict(value=pg * fw / sorted(tg)[1] / 1e6, unit="M rays/s",
+                             note=f"the oracle's eager PyTorch graph + autograd on this MI355X, {pg * fw} rays of the same workload")
+            del gsrc, glv
+            torch.cuda.empty_cache()
+        except Exception as e:                      # informational only: never fail the bench on it
+            eager_gpu = dict(value=None, note=f"not measured: {type(e).__name__}: {e}"[:200])
     try:
         model = [ln.split(":")[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    base = dict(value=p * fw / med / 1e6, unit="M rays/s", cores=cores, kind="port",
+    base = dict(value=p * fw / med / 1e6, unit="M rays/s", cores=cores, kind="port", eager_pytorch_on_gpu=eager_gpu,
                 sample=f"{p * fw} rays ({p} pupil points x {fw} field-wavelengths) of the same workload, fwd+bwd, "
                        f"median of 3 after 1 warm-up, torch threads={cores}, cpu='{model}'")
     return base, grad_check
