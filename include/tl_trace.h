@@ -138,10 +138,14 @@ int tl_trace_bwd(const tl_problem *p,
  * No per-surface state is kept, so the kernel runs at twice the occupancy and needs no bit-exact
  * re-derivation of the forward; the reconstructed states differ from the forward's by rounding only,
  * which perturbs the gradients at the 1e-6 level (tested) -- except for ill-conditioned rays (moment 9 of
- * tl_trace_fwd), where it would reach 1e-4: pass the forward's moments as `moments_fwd` (nullable) and the
- * call also enqueues the checkpoint kernel of tl_trace_bwd; the two launches read the count ON THE DEVICE
- * and only one of them does the work (no host synchronisation; the idle launch retires in microseconds).
+ * tl_trace_fwd), where it would reach 1e-4.  The call therefore always enqueues the checkpoint kernel of
+ * tl_trace_bwd behind the walk-back kernel; both decide ON THE DEVICE which of them does the work (no host
+ * synchronisation; the idle launch retires in microseconds).  The checkpoint kernel takes over when
+ *   - `moments_fwd` (the forward's moments, nullable) counts an ill-conditioned live ray, or
+ *   - the walk-back met a non-finite adjoint (it then flags a word at the end of the workspace).
+ * Pass `moments_fwd` whenever it is available: without it an ill-conditioned fan is walked back anyway.
  * All-spherical lenses, allow_backward = 1, aggregate = 0 only (TL_EINVAL otherwise: use tl_trace_bwd).
+ * Workspace: tl_workspace_bytes(p); its contents need not be initialised.
  */
 int tl_trace_bwd_from_outputs(const tl_problem *p,
                               const float *gx, const float *gy, const float *gcx, const float *gcy,
