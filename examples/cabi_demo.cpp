@@ -19,7 +19,7 @@ template <class T> static T *to_device(const std::vector<T> &h)
 {
     T *d = nullptr;
     if (hipMalloc((void **)&d, h.size() * sizeof(T)) != hipSuccess) return nullptr;
-    hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     return d;
 }
 
