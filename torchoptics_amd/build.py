@@ -33,7 +33,6 @@ COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno
 # fast  : contraction on; the kernels call v_rcp / v_sqrt explicitly
 UNITS = {
     "tl_strict.hip": ["-ffp-contract=off"],
-    "tl_strict_wb.hip": ["-ffp-contract=fast"],     # strict mode's walk-back kernel only (see the file)
     "tl_fast.hip": ["-ffp-contract=fast"],
     "tl_api.hip": [],
 }

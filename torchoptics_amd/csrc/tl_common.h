@@ -32,11 +32,3 @@ static inline int tl_bwd_row(int ns, bool asph) { return (asph ? 8 : 3) * ns + 3
     }
 TL_DECLARE_MODE(tl_strict)
 TL_DECLARE_MODE(tl_fast)
-
-// strict mode's walk-back kernel, built separately so that it may contract (tl_strict_wb.hip)
-namespace tl_strict_wb {
-int api_walk_back(const tl_problem &p, const float *gx, const float *gy, const float *gcx, const float *gcy,
-                  const double *gmom, const float *fx, const float *fy, const float *fcx, const float *fcy,
-                  const uint8_t *fok, const double *fmom, float *gxin, float *gyin, double *part_inv,
-                  unsigned *poison, unsigned token, int nbx, int R, hipStream_t st);
-}

@@ -4,7 +4,6 @@
 #include "tl_common.h"
 #define TL_NS tl_strict_impl
 #define TL_FAST 0
-#define TL_WALK_BACK tl_strict_wb::api_walk_back      // the contracting build of the walk-back kernel
 #include "tl_kernels.inc"
 namespace tl_strict {
 int api_fwd(const tl_problem &p, float *x, float *y, float *cx, float *cy, uint8_t *ok, uint8_t *back,
