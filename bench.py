@@ -219,7 +219,7 @@ def main():
     # ---- roofline of the dominant kernel (trace_bwd_kernel), per launch, from live event timing
     fw = meta["F"] * meta["W"]
     from torchoptics_amd import ops as _ops
-    inv = _ops.get_backward_algorithm() == "inverse" and "kappa" not in args
+    inv = _ops.get_backward_algorithm() == "inverse"       # aspheric rows are walked back too
     # algorithmic bytes per ray (DESIGN.md "bytes per unit"): forward writes x,y,cx,cy,ok,back and reads x_in,y_in;
     # the walk-back backward reads x_in,y_in and the forward's x,y,cx,cy,ok; the checkpoint backward only x_in,y_in
     b_fwd, b_bwd = 18.0 + 8.0 / fw, (17.0 if inv else 0.0) + 8.0 / fw

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 8
+#define TL_ABI_VERSION 9
 #define TL_MAX_SURFACES 32       /* rows per lens the backward kernels are built for */
 #define TL_NMOM 10               /* per-field sums, see tl_trace_fwd */
 #define TL_MAX_POLY 4            /* even aspheric terms a4,a6,a8,a10 */
@@ -144,7 +144,8 @@ int tl_trace_bwd(const tl_problem *p,
  *   - `moments_fwd` (the forward's moments, nullable) counts an ill-conditioned live ray, or
  *   - the walk-back met a non-finite adjoint (it then flags a word at the end of the workspace).
  * Pass `moments_fwd` whenever it is available: without it an ill-conditioned fan is walked back anyway.
- * All-spherical lenses, allow_backward = 1, aggregate = 0 only (TL_EINVAL otherwise: use tl_trace_bwd).
+ * allow_backward = 1 and aggregate = 0 only (TL_EINVAL otherwise: use tl_trace_bwd).  Aspheric rows are walked
+ * back too (Newton on the reversed ray; g_kappa, g_poly as in tl_trace_bwd, required iff p->surf_kind).
  * Workspace: tl_workspace_bytes(p); its contents need not be initialised.
  */
 int tl_trace_bwd_from_outputs(const tl_problem *p,
@@ -153,6 +154,7 @@ int tl_trace_bwd_from_outputs(const tl_problem *p,
                               const float *x_fwd, const float *y_fwd, const float *cx_fwd, const float *cy_fwd,
                               const uint8_t *ok_fwd, const double *moments_fwd,
                               float *g_c, float *g_t, float *g_mu, float *g_z, float *g_cx, float *g_cy,
+                              float *g_kappa, float *g_poly,
                               float *g_x_in, float *g_y_in,
                               void *workspace, size_t workspace_bytes, void *stream);
 

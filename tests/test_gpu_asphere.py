@@ -67,8 +67,13 @@ def test_asphere_forward_matches_oracle(ta, case):
     assert not got[0].cpu()[~ok_g].any()
 
 
-def test_asphere_gradients_match_oracle_autograd(ta):
+@pytest.mark.parametrize("algo", ["inverse", "checkpoint"])
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_asphere_gradients_match_oracle_autograd(ta, algo, mode):
+    """Both backward algorithms on aspheric rows: the walk-back (Newton on the reversed ray, default) and the
+    checkpoint kernel, against the oracle's fp64 autograd."""
     from oracle import trace_oracle as orc
+    from torchoptics_amd import ops
     ins, mask = _inputs()
     S = ins[5].shape[-1]
     kap0, pol0, kind = asphere_params(S)
@@ -83,14 +88,21 @@ def test_asphere_gradients_match_oracle_autograd(ta):
         res[tag] = [q.grad for q in lv]
     lv = [ins[2], ins[4], ins[5], ins[6], ins[7], kap0, pol0]
     lv = [q.to(DEV).requires_grad_(True) for q in lv]
-    x, y, cx, cy, ok, back = ta.trace_skew(ins[0].to(DEV), ins[1].to(DEV), lv[0], ins[3].to(DEV), lv[1], lv[2], lv[3],
-                                           lv[4], mask.to(DEV), kappa=lv[5], poly=lv[6])
-    ta.compute_rms2d(x, y, ok).backward()
+    ops.set_backward_algorithm(algo)
+    try:
+        x, y, cx, cy, ok, back = ta.trace_skew(ins[0].to(DEV), ins[1].to(DEV), lv[0], ins[3].to(DEV), lv[1], lv[2],
+                                               lv[3], lv[4], mask.to(DEV), kappa=lv[5], poly=lv[6], mode=mode)
+        assert x.grad_fn.use_inv is (algo == "inverse")
+        ta.compute_rms2d(x, y, ok).backward()
+    finally:
+        ops.set_backward_algorithm("inverse")
+    tol = 2e-5 if mode == "strict" else 2e-4
     for n, q, g32, g64 in zip(names, lv, res["f32"], res["f64"]):
         got = q.grad.cpu()
         e64, noise = rel_l2(got.numpy(), g64.numpy()), rel_l2(g32.numpy(), g64.numpy())
-        print(f"asphere d/d{n}: vs fp64 {e64:.2e} (oracle fp32 itself {noise:.2e})")
-        assert e64 <= 2e-5 + 2 * noise, f"d/d{n}: {e64:.2e} vs oracle fp32 noise {noise:.2e}"
+        print(f"asphere {algo} {mode} d/d{n}: vs fp64 {e64:.2e} (oracle fp32 itself {noise:.2e})")
+        lim = tol if n not in ("z", "cy") else max(tol, 1e-3)          # launch conditions: cancellation-heavy
+        assert e64 <= lim + 2 * noise, f"{algo} {mode} d/d{n}: {e64:.2e} vs oracle fp32 noise {noise:.2e}"
     # rows that are not aspheric get exactly zero kappa / poly gradient
     nz = torch.tensor(kind, dtype=torch.bool)
     assert lv[5].grad.cpu()[~nz].abs().max().item() == 0 and lv[6].grad.cpu()[~nz].abs().max().item() == 0

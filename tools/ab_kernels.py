@@ -62,6 +62,8 @@ def main():
             f.restype = res
             if fn == "tl_trace_fwd" and ver < 5:       # older ABI: no `stacks` argument
                 argt = argt[:8] + argt[9:]
+            if fn == "tl_trace_bwd_from_outputs" and ver < 9:   # older ABI: no g_kappa, g_poly
+                argt = argt[:-5] + argt[-3:]
             f.argtypes = argt
         dll._ver = ver
         libs[name] = dll
@@ -81,7 +83,8 @@ def main():
     def bwd_inv(dll):
         rc = dll.tl_trace_bwd_from_outputs(C.byref(prob), None, None, None, None, P_(gmom), P_(outs[0]), P_(outs[1]),
                                            P_(outs[2]), P_(outs[3]), P_(flags[0]), P_(mom), P_(g_c), P_(g_t), P_(g_mu),
-                                           P_(g_z), P_(g_cx), P_(g_cy), None, None, P_(ws), ws.numel(), st)
+                                           P_(g_z), P_(g_cx), P_(g_cy), *((None, None) if dll._ver >= 9 else ()),
+                                           None, None, P_(ws), ws.numel(), st)
         assert rc == 0, dll.tl_last_error()
 
     res = {n: {"fwd": [], "bwd": [], "bwd_inv": []} for n in libs}

@@ -134,7 +134,9 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
         double n = 0.0;
         if (fmom)
             for (int f = 0; f < F; ++f) n += fmom[(size_t)f * TL_NMOM + 9];
-        if (n > 0.0 || (poison && *poison == token)) { part = alt_part; NS = alt_NS; ncol = 3 * alt_NS + 3; nbx = alt_nbx; }
+        if (n > 0.0 || (poison && *poison == token)) {
+            part = alt_part; NS = alt_NS; ncol = (g_kappa ? 8 : 3) * alt_NS + 3; nbx = alt_nbx;
+        }
     }
     int b = blockIdx.x;
     float *out;
@@ -252,7 +254,7 @@ size_t tl_workspace_bytes(const tl_problem *p)
     const size_t fw = (size_t)p->F * p->W;
     const size_t a = fw * pf.nbx * TL_NMOM * sizeof(double);
     const size_t b = fw * pb.nbx * (size_t)tl_bwd_row(ns < 0 ? TL_MAX_SURFACES : ns, p->surf_kind != nullptr) * sizeof(double);
-    const size_t c = fw * pb.nbx * (size_t)(3 * p->S + 3) * sizeof(double);   // walk-back kernel next to its fallback
+    const size_t c = fw * pb.nbx * (size_t)((p->surf_kind ? 8 : 3) * p->S + 3) * sizeof(double);   // walk-back kernel next to its fallback
     return (a > b + c ? a : b + c) + 256;
 }
 
@@ -338,17 +340,19 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
 int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float *gy, const float *gcx, const float *gcy,
                               const double *g_moments, const float *x_fwd, const float *y_fwd, const float *cx_fwd,
                               const float *cy_fwd, const uint8_t *ok_fwd, const double *moments_fwd, float *g_c,
-                              float *g_t, float *g_mu,
-                              float *g_z, float *g_cx, float *g_cy, float *g_x_in, float *g_y_in, void *workspace,
-                              size_t workspace_bytes, void *stream)
+                              float *g_t, float *g_mu, float *g_z, float *g_cx, float *g_cy, float *g_kappa,
+                              float *g_poly, float *g_x_in, float *g_y_in, void *workspace, size_t workspace_bytes,
+                              void *stream)
 {
     int rc = check_problem(p);
     if (rc) return rc;
     if (!g_c || !g_t || !g_mu || !g_z || !g_cx || !g_cy) return fail(TL_EINVAL, "a parameter-gradient output is NULL");
     if (!x_fwd || !y_fwd || !cx_fwd || !cy_fwd || !ok_fwd) return fail(TL_EINVAL, "the forward outputs x, y, cx, cy, ok are required");
-    if (p->surf_kind || p->aggregate || !p->allow_backward)
-        return fail(TL_EINVAL, "tl_trace_bwd_from_outputs: all-spherical lenses with allow_backward_rays and no penalty term only");
-    if (p->P == 0) return tl_trace_bwd(p, gx, gy, gcx, gcy, g_moments, g_c, g_t, g_mu, g_z, g_cx, g_cy, nullptr, nullptr,
+    if (p->aggregate || !p->allow_backward)
+        return fail(TL_EINVAL, "tl_trace_bwd_from_outputs: allow_backward_rays and no penalty term only");
+    if ((g_kappa || g_poly) && !p->surf_kind) return fail(TL_EINVAL, "g_kappa / g_poly need aspheric rows (surf_kind)");
+    if (p->surf_kind && (!g_kappa || !g_poly)) return fail(TL_EINVAL, "aspheric rows need g_kappa and g_poly outputs");
+    if (p->P == 0) return tl_trace_bwd(p, gx, gy, gcx, gcy, g_moments, g_c, g_t, g_mu, g_z, g_cx, g_cy, g_kappa, g_poly,
                                        g_x_in, g_y_in, workspace, workspace_bytes, stream);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSetDevice(p->device);
@@ -356,7 +360,8 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     const Plan pl = plan_bwd(p);
     // the fallback is launched too and normally retires at once: a quarter of the blocks keeps that idle launch cheap
     const Plan pk = make_plan(p->P, p->F * p->W, 1024, 256);
-    const int ncol = 3 * p->S + 3, ns = tl_bwd_bucket(p->S), ncol_ck = tl_bwd_row(ns, false);
+    const bool asph = p->surf_kind != nullptr;
+    const int ncol = (asph ? 8 : 3) * p->S + 3, ns = tl_bwd_bucket(p->S), ncol_ck = tl_bwd_row(ns, asph);
     const size_t rows = (size_t)p->F * p->W * pl.nbx, rows_ck = (size_t)p->F * p->W * pk.nbx;
     const size_t need_inv = rows * ncol * sizeof(double), need_ck = rows_ck * ncol_ck * sizeof(double);
     if (!workspace || workspace_bytes < need_inv + need_ck + sizeof(double))
@@ -372,9 +377,9 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
                    : tl_strict::api_bwd_inv(*p, gx, gy, gcx, gcy, g_moments, x_fwd, y_fwd, cx_fwd, cy_fwd, ok_fwd,
                                             moments_fwd, g_x_in, g_y_in, part, part_ck, poison, token, pl.nbx, pl.R, pk.nbx, pk.R, st);
     if (herr) return hip_fail(herr, "trace_bwd_inv_kernel launch");
-    const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F;
+    const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0);
     hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout), dim3(kBlock), 0, st, part, p->S, p->F, p->W, p->S, pl.nbx, g_c, g_t,
-                       g_mu, g_z, g_cx, g_cy, ncol, (float *)nullptr, (float *)nullptr, (const double *)part_ck, ns,
+                       g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly, (const double *)part_ck, ns,
                        moments_fwd, (const unsigned *)poison, token, pk.nbx);
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");

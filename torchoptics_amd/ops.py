@@ -21,7 +21,7 @@ _MODES = {"strict": _lib.MODE_STRICT, "fast": _lib.MODE_FAST}
 _default_mode = os.environ.get("TORCHOPTICS_AMD_MODE", "strict")
 # backward algorithm: "checkpoint" = re-trace forwards keeping the per-surface states in registers;
 # "inverse" = walk back from the forward kernel's outputs (tl_trace_bwd_from_outputs), used whenever the
-# problem allows it (all-spherical, allow_backward_rays, no penalty term, per-ray outputs were produced)
+# problem allows it (allow_backward_rays, no penalty term, per-ray outputs were produced)
 _bwd_algo = os.environ.get("TORCHOPTICS_AMD_BWD", "inverse")
 
 
@@ -170,7 +170,7 @@ class TraceFunction(torch.autograd.Function):
         _lib.check(rc, "tl_trace_fwd")
         # per-ray input gradients (ray aiming: a handful of rays) keep the checkpoint algorithm: extreme rays
         # amplify the reconstruction rounding of the walk-back to ~1e-4 in d/dx_in, d/dy_in
-        use_inv = (_bwd_algo == "inverse" and want_rays and kind_u8 is None and not aggregate and allow_back
+        use_inv = (_bwd_algo == "inverse" and want_rays and not aggregate and allow_back
                    and not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         fwd_out = (fp[0], fp[1], fp[2], fp[3], bp[0], moments) if use_inv else (None,) * 6
         ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, *fwd_out)
@@ -221,8 +221,8 @@ class TraceFunction(torch.autograd.Function):
                 rc = lib.tl_trace_bwd_from_outputs(
                     C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd), _lib.ptr(gmd),
                     _lib.ptr(fx), _lib.ptr(fy), _lib.ptr(fcx), _lib.ptr(fcy), _lib.ptr(fok), _lib.ptr(fmom),
-                    *[_lib.ptr(q) for q in parts[:6]], _lib.ptr(gxin), _lib.ptr(gyin), _lib.ptr(ws), ws.numel(),
-                    _stream_ptr(dev))
+                    *[_lib.ptr(q) for q in parts[:6]], _lib.ptr(g_kappa), _lib.ptr(g_poly), _lib.ptr(gxin),
+                    _lib.ptr(gyin), _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
             else:
                 rc = lib.tl_trace_bwd(C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd),
                                       _lib.ptr(gmd), *[_lib.ptr(q) for q in parts[:6]], _lib.ptr(g_kappa),
