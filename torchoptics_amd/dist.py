@@ -54,10 +54,18 @@ def all_reduce_grads(params: Iterable[torch.Tensor], group=None) -> None:
     params = [p for p in params if p.grad is not None]
     if not params:
         return
-    flat = torch.cat([p.grad.reshape(-1).to(torch.float64) for p in params])
+    grads = [p.grad for p in params]
+    # four launches + one collective, whatever the number of leaves: cat, widen, all-reduce, narrow, scatter back
+    flat = torch.cat([g.reshape(-1) for g in grads]).to(torch.float64)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    off = 0
-    for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].reshape(p.grad.shape).to(p.grad.dtype))
+    flat = flat.to(grads[0].dtype)
+    views, off = [], 0
+    for g in grads:
+        n = g.numel()
+        views.append(flat[off:off + n].view(g.shape))
         off += n
+    if all(g.dtype == grads[0].dtype for g in grads):
+        torch._foreach_copy_(grads, views)
+    else:
+        for g, v in zip(grads, views):
+            g.copy_(v)
