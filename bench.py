@@ -270,6 +270,10 @@ def main():
             also[wname] = dict(value=nr * a.steps / adt / 1e6, unit="M rays/s", ms_per_step=adt / a.steps * 1e3,
                                fwd_kernel_ms=akm.get("fwd"), bwd_kernel_ms=akm.get("bwd"), rays=nr, rows=meta2["S"],
                                F=meta2["F"], W=meta2["W"], rms=float(arms.item()), arith_mode=a.mode)
+            if akm.get("fwd") and akm.get("bwd"):
+                # small workloads are bound by the eager Python/autograd chain (~0.25-0.4 ms of host time per
+                # step, box dependent), not by the GPU: also quote what the two trace kernels alone sustain
+                also[wname]["trace_kernels_only_value"] = nr / world / (akm["fwd"] + akm["bwd"]) / 1e3
         args, meta, leaves, asph, n_per_field_total = main_state
 
     # the same step replayed from a HIP graph, measured in a CHILD process (a capture failure of the

@@ -195,7 +195,8 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
     if cxv.numel() not in (1, F) or cyv.numel() not in (1, F):
         raise ValueError("cx, cy must be per-field [1,F,1,1] or a single value")
     mu2 = mu.reshape(mu.shape[3], S).expand(W, S).contiguous()
-    mask_u8 = mask.reshape(-1).to(torch.uint8).contiguous()
+    mask_u8 = mask.reshape(-1).contiguous()
+    mask_u8 = mask_u8.view(torch.uint8) if mask_u8.dtype == torch.bool else mask_u8.to(torch.uint8)   # bool: no copy
     kap = pol = kind_u8 = None
     if kappa is not None or poly is not None:
         kap = _as_f32(kappa, 'kappa').reshape(S).contiguous() if kappa is not None else torch.zeros(S, device=c.device)
