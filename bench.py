@@ -273,7 +273,7 @@ def main():
             if akm.get("fwd") and akm.get("bwd"):
                 # small workloads are bound by the eager Python/autograd chain (~0.25-0.4 ms of host time per
                 # step, box dependent), not by the GPU: also quote what the two trace kernels alone sustain
-                also[wname]["trace_kernels_only_value"] = nr / world / (akm["fwd"] + akm["bwd"]) / 1e3
+                also[wname]["trace_kernels_only_value"] = nr / (akm["fwd"] + akm["bwd"]) / 1e3
         args, meta, leaves, asph, n_per_field_total = main_state
 
     # the same step replayed from a HIP graph, measured in a CHILD process (a capture failure of the
