@@ -47,6 +47,34 @@ def test_newton_rows_on_spherical_data_match_closed_form_kernel(ta, mode):
     assert (a[2] - b[2]).abs().max().item() < 2e-6 and (a[3] - b[3]).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize("algo", ["inverse", "checkpoint"])
+def test_newton_rows_everywhere_give_the_spherical_gradients(ta, algo):
+    """Every row but the flat stop traced by Newton with zero conic / polynomial terms: first row, last row and
+    consecutive aspheric rows in the backward (walk-back: hit_asph at the start, between neighbours and into the
+    launch conditions).  The gradients w.r.t. c, t, mu must equal the closed-form lens's."""
+    from torchoptics_amd import ops
+    ins, mask = _inputs()
+    S = ins[5].shape[-1]
+    kind = torch.ones(S, dtype=torch.bool)
+    kind[4] = False
+    grads = {}
+    ops.set_backward_algorithm(algo)
+    try:
+        for tag in ("sph", "newton"):
+            dev = [a.to(DEV) for a in ins]
+            lv = [dev[i].clone().requires_grad_(True) for i in (5, 6, 7)]
+            extra = {} if tag == "sph" else dict(kappa=torch.zeros(S, device=DEV), poly=torch.zeros(S, 4, device=DEV),
+                                                 surf_kind=kind)
+            x, y, cx, cy, ok, back = ta.trace_skew(*dev[:5], *lv, mask.to(DEV), **extra)
+            assert x.grad_fn.use_inv is (algo == "inverse")
+            ta.compute_rms2d(x, y, ok).backward()
+            grads[tag] = [q.grad.cpu().numpy() for q in lv]
+    finally:
+        ops.set_backward_algorithm("inverse")
+    for n, a, b in zip(("c", "t", "mu"), grads["newton"], grads["sph"]):
+        assert np.isfinite(a).all() and rel_l2(a, b) < 2e-5, f"{algo} d/d{n}: {rel_l2(a, b):.2e}"
+
+
 @pytest.mark.parametrize("case", ["G4_tessar_32x32", "G5_cooke_failures"])
 def test_asphere_forward_matches_oracle(ta, case):
     from oracle import trace_oracle as orc
