@@ -178,17 +178,49 @@ class Specs:
                      self.vig_down[index], self.vig_x[index])
 
 
+# Results of the last few gradient-free conversions (padding of constant nd / v, dispersion of constant
+# glasses): an optimisation loop re-builds the same Lens every step, and each of these is several tiny
+# launches whose host cost (~8 us each) is what bounds small workloads.  Keyed by storage, version counter,
+# shape and dtype, so an in-place update of the source invalidates the entry.
+_memo = {}
+
+
+def _memo_key(tag, *tensors, extra=()):
+    return (tag, extra) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device) for t in tensors)
+
+
+def _memoised(key, tensors, fn):
+    if any(t.requires_grad for t in tensors):
+        return fn()
+    hit = _memo.get(key)
+    if hit is None or hit[0]._version != hit[1]:         # never computed, or somebody wrote into the cached result
+        if len(_memo) > 64:
+            _memo.clear()
+        out = fn()
+        hit = _memo[key] = (out, out._version)
+    return hit[0]
+
+
 def _pad_from_flat(flat: torch.Tensor, mask_t: torch.Tensor, fill: float, idx: torch.Tensor) -> torch.Tensor:
     """flat [n] (or [n, k]) -> padded [lens, row] (or [lens, row, k]) with `fill` elsewhere."""
     tail = tuple(flat.shape[1:])
-    base = torch.full((mask_t.numel(), *tail), fill, dtype=flat.dtype, device=mask_t.device)
-    return base.index_copy(0, idx, flat.to(mask_t.device)).reshape(*mask_t.shape, *tail)
+    flat = flat.to(mask_t.device)
+    if idx.numel() == mask_t.numel():            # nothing to pad (one lens, or equal-length lenses): a view
+        return flat.reshape(*mask_t.shape, *tail)
+
+    def pad():
+        base = torch.full((mask_t.numel(), *tail), fill, dtype=flat.dtype, device=mask_t.device)
+        return base.index_copy(0, idx, flat).reshape(*mask_t.shape, *tail)
+    return _memoised(_memo_key("pad", flat, idx, extra=(fill if fill == fill else "nan", tuple(mask_t.shape))), (flat,), pad)
 
 
 def _take(padded: torch.Tensor, width: int, idx: torch.Tensor) -> torch.Tensor:
     """The entries `idx` (flat positions in the [lens, width] layout) of padded[:, :width(, k)]."""
     cut = padded[:, :width]
-    return cut.reshape(cut.shape[0] * width, *cut.shape[2:]).index_select(0, idx)
+    flat = cut.reshape(cut.shape[0] * width, *cut.shape[2:])
+    if idx.numel() == flat.shape[0]:             # every entry is kept: a view
+        return flat
+    return _memoised(_memo_key("take", padded, idx, extra=(width,)), (padded,), lambda: flat.index_select(0, idx))
 
 
 @dataclass
@@ -310,13 +342,16 @@ class Lens:
         A, B follow from nd and the Abbe number (lens_modeling.py:355-374).  Air rows give 1;
         rows whose Abbe number is 0 are dispersion-free (n = nd).
         """
-        b = (self.nd - 1) / (self.v * (_LAMBDA_F ** -2 - _LAMBDA_C ** -2))
-        a = self.nd - b / _LAMBDA_D ** 2
-        lam = const_tensor(list(wavelengths), a.dtype, a.device, (1, 1, len(wavelengths)))
-        n = a[..., None] + b[..., None] / lam ** 2
-        n = torch.where(self.structure.mask_G_torch[..., None], n, torch.ones_like(n))
-        dispersive = (self.v != 0)[..., None]
-        return torch.where(dispersive, n, self.nd[..., None].expand_as(n))
+        def dispersion():
+            b = (self.nd - 1) / (self.v * (_LAMBDA_F ** -2 - _LAMBDA_C ** -2))
+            a = self.nd - b / _LAMBDA_D ** 2
+            lam = const_tensor(list(wavelengths), a.dtype, a.device, (1, 1, len(wavelengths)))
+            n = a[..., None] + b[..., None] / lam ** 2
+            n = torch.where(self.structure.mask_G_torch[..., None], n, torch.ones_like(n))
+            dispersive = (self.v != 0)[..., None]
+            return torch.where(dispersive, n, self.nd[..., None].expand_as(n))
+        key = _memo_key("n", self.nd, self.v, self.structure.mask_G_torch, extra=tuple(float(w) for w in wavelengths))
+        return _memoised(key, (self.nd, self.v), dispersion)
 
     # ---- first-order properties (paraxial.py) ----------------------------------
     @property
