@@ -1,0 +1,77 @@
+"""
+tl_pupil_position (one-kernel paraxial entrance-pupil position + its gradient) against the PyTorch ABCD chain
+it replaces on the GPU.  The chain itself is pinned against the reference by fixture G9 on the CPU
+(test_host_logic / test_oracle_golden); here: same value to fp32 rounding, same gradients w.r.t. c, t, nd.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from yaml_free_lenses import build
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("name", ["cooke", "tessar", "doublet", "double_gauss", "zoom20"])
+def test_pupil_position_kernel_matches_abcd_chain(name):
+    from torchoptics_amd import paraxial, prescriptions as P
+    from torchoptics_amd.lens_modeling import Lens
+    if name in ("double_gauss", "zoom20"):
+        lens0, specs, leaves = getattr(P, name)(DEV)
+        st, flat = lens0.structure, [leaves[k].detach().clone() for k in ("c", "t", "nd", "v")]
+    else:
+        lens0, specs, leaves = build(name, DEV)
+        st, flat = lens0.structure, [leaves[k].detach().clone() for k in ("c", "t", "nd", "v")]
+    res = {}
+    for tag in ("kernel", "chain"):
+        lv = [q.clone().requires_grad_(True) for q in flat[:3]]
+        lens = Lens(st, lv[0], lv[1], lv[2], flat[3])
+        if tag == "kernel":
+            z = paraxial.compute_pupil_position(lens)
+            assert type(z.grad_fn).__name__ != "DivBackward0"          # went through the fused op
+        else:
+            front = lens.up_to_stop()
+            m = paraxial.reduce_abcd(paraxial.interface_propagation_abcd(
+                front.c.double(), front.t.double(), paraxial._with_air_in_front(front.nd.double())))
+            z = (m[:, 0, 1] / m[:, 0, 0]).float()
+        (z.sum() * 1.7).backward()
+        res[tag] = (z.detach().cpu().numpy(), [q.grad.cpu().numpy() if q.grad is not None else None for q in lv])
+    zk, zc = res["kernel"][0], res["chain"][0]
+    assert zk.shape == zc.shape and np.allclose(zk, zc, rtol=2e-7, atol=1e-9)          # both round an fp64 result once
+    for n, a, b in zip(("c", "t", "nd"), res["kernel"][1], res["chain"][1]):
+        if b is None or np.abs(b).max() == 0:
+            assert a is None or np.abs(a).max() == 0
+            continue
+        assert rel_l2(a, b) < 1e-6, f"{name} d z/d{n}: {rel_l2(a, b):.2e}"
+
+
+def test_pupil_position_feeds_trace_rays_and_the_adam_step():
+    """End to end: the gradient of the RMS spot w.r.t. c, t through trace_rays is the same whether z comes from
+    the fused op or from the elementwise chain."""
+    import torchoptics_amd as ta
+    from torchoptics_amd import paraxial, prescriptions as P, ray_tracing as rt
+    lens0, specs, leaves = P.double_gauss(DEV)
+    tracer = ta.RayTracer(mode="circular", n_rays=(32, 32), rel_fields=(0., 0.707, 1.), wavelengths=("C", "d", "F"),
+                          default_device=DEV)
+    grads = {}
+    orig = paraxial.compute_pupil_position
+    for tag in ("kernel", "chain"):
+        c, t = leaves["c"].detach().clone().requires_grad_(True), leaves["t"].detach().clone().requires_grad_(True)
+        lens = ta.Lens(lens0.structure, c, t, leaves["nd"].detach(), leaves["v"].detach())
+        if tag == "chain":
+            def chain(lz):
+                front = lz.up_to_stop()
+                m = paraxial.reduce_abcd(paraxial.interface_propagation_abcd(front.c, front.t,
+                                                                            paraxial._with_air_in_front(front.nd)))
+                return m[:, 0, 1] / m[:, 0, 0]
+            rt.compute_pupil_position = chain
+        try:
+            x, y, cx, cy, ok, back = tracer.trace_rays(specs, lens)
+            rt.compute_rms2d(x, y, ok).backward()
+        finally:
+            rt.compute_pupil_position = orig
+        grads[tag] = [c.grad.cpu().numpy(), t.grad.cpu().numpy()]
+    for a, b in zip(grads["kernel"], grads["chain"]):
+        assert rel_l2(a, b) < 5e-5           # the fp32 chain's own rounding of z moves the spot gradient at this level

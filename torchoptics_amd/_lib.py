@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtltrace.so")
 
-TL_ABI_VERSION = 9
+TL_ABI_VERSION = 10
 TL_NMOM = 10
 TL_MAX_SURFACES = 32
 TL_MAX_POLY = 4
@@ -47,6 +47,7 @@ _SIGNATURES = {
     "tl_spot_moments": (C.c_int, [C.c_int32] * 4 + [_VP] * 3 + [C.c_int64] * 3 + [_VP, _VP, C.c_size_t, _VP]),
     "tl_spot_rms": (C.c_int, [C.c_int32, C.c_int32, C.c_double, _VP, _VP, _VP, _VP]),
     "tl_spot_seed": (C.c_int, [C.c_int32] * 4 + [_VP] * 3 + [C.c_int64] * 3 + [_VP] * 4),
+    "tl_pupil_position": (C.c_int, [C.c_int32] * 2 + [_VP] * 9),
 }
 EXPORTS = tuple(_SIGNATURES)
 

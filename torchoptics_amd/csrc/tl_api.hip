@@ -238,6 +238,55 @@ __global__ __launch_bounds__(kBlock) void spot_seed_kernel(int P, int W, const f
 }  // namespace
 
 // =================================================================== C ABI
+// Paraxial entrance-pupil position (the `z` argument of the trace): z = B/A of the ordered product
+// M = M_{K-1} ... M_0 of the rows in front of the stop, M_k = [[1 + P t, r t], [P, r]], r = n_k / n_{k+1},
+// P = c (r - 1)  (ray_tracing_lite.py:301-350, lens_modeling.py ABCD).  K <= 32 rows: one thread, fp64 inside.
+// Replaces ~25 tiny elementwise / 2x2-matmul launches of the host chain and ~60 of its autograd backward.
+__global__ void pupil_position_kernel(int K, const float *__restrict__ c, const float *__restrict__ t,
+                                      const float *__restrict__ n, float *__restrict__ z,
+                                      const float *__restrict__ g_z, float *__restrict__ g_c,
+                                      float *__restrict__ g_t, float *__restrict__ g_n)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double R[TL_MAX_SURFACES][4];            // R[k] = M_{k-1} ... M_0 (row-major a b / c d), R[0] = I
+    double a = 1.0, b = 0.0, cc = 0.0, d = 1.0;
+    for (int k = 0; k < K; ++k) {
+        R[k][0] = a; R[k][1] = b; R[k][2] = cc; R[k][3] = d;
+        const double r = (double)n[k] / (double)n[k + 1], P = (double)c[k] * (r - 1.0), tk = (double)t[k];
+        const double m00 = 1.0 + P * tk, m01 = r * tk, m10 = P, m11 = r;
+        const double na = m00 * a + m01 * cc, nb = m00 * b + m01 * d, nc = m10 * a + m11 * cc, nd = m10 * b + m11 * d;
+        a = na; b = nb; cc = nc; d = nd;
+    }
+    if (z) z[0] = (float)(b / a);
+    if (!g_z) return;
+    // reverse mode: G = d z / d M_full, carried down as G_k = L_k^T G with L_k = M_{K-1} ... M_{k+1}
+    const double gz = (double)g_z[0];
+    double G00 = -gz * b / (a * a), G01 = gz / a, G10 = 0.0, G11 = 0.0;
+    for (int k = 0; k <= K; ++k) g_n[k] = 0.0f;
+    double carry_n = 0.0;                     // d/d n[k+1] collected from row k+1 (the "n_k" side of that row)
+    for (int k = K - 1; k >= 0; --k) {
+        const double nk = (double)n[k], nk1 = (double)n[k + 1];
+        const double r = nk / nk1, ck = (double)c[k], tk = (double)t[k], P = ck * (r - 1.0);
+        // dM_k = G_k R_k^T
+        const double d00 = G00 * R[k][0] + G01 * R[k][1], d01 = G00 * R[k][2] + G01 * R[k][3];
+        const double d10 = G10 * R[k][0] + G11 * R[k][1], d11 = G10 * R[k][2] + G11 * R[k][3];
+        const double dP = d00 * tk + d10;
+        const double dt = d00 * P + d01 * r;
+        const double dr = d01 * tk + d11 + dP * ck;
+        g_c[k] = (float)(dP * (r - 1.0));
+        g_t[k] = (float)dt;
+        // r = n_k / n_{k+1}
+        g_n[k + 1] = (float)(carry_n - dr * nk / (nk1 * nk1));
+        carry_n = dr / nk1;
+        // G_{k-1} = M_k^T G_k
+        const double m00 = 1.0 + P * tk, m01 = r * tk, m10 = P, m11 = r;
+        const double h00 = m00 * G00 + m10 * G10, h01 = m00 * G01 + m10 * G11;
+        const double h10 = m01 * G00 + m11 * G10, h11 = m01 * G01 + m11 * G11;
+        G00 = h00; G01 = h01; G10 = h10; G11 = h11;
+    }
+    g_n[0] = (float)carry_n;
+}
+
 extern "C" {
 
 int tl_version(void) { return TL_ABI_VERSION; }
@@ -432,6 +481,20 @@ int tl_spot_seed(int32_t device, int32_t F, int32_t P, int32_t W, const float *x
                        P, W, x, y, ok, s_f, s_p, s_w, g_moments, gx, gy);
     const int herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "spot_seed_kernel launch");
+    return TL_OK;
+}
+
+int tl_pupil_position(int32_t device, int32_t K, const float *c, const float *t, const float *n, float *z,
+                      const float *g_z, float *g_c, float *g_t, float *g_n, void *stream)
+{
+    if (K < 1 || K > TL_MAX_SURFACES || !c || !t || !n) return fail(TL_EINVAL, "tl_pupil_position: bad argument");
+    if (!z && !g_z) return fail(TL_EINVAL, "tl_pupil_position: neither z nor g_z given");
+    if (g_z && (!g_c || !g_t || !g_n)) return fail(TL_EINVAL, "tl_pupil_position: g_z needs g_c, g_t and g_n");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    hipLaunchKernelGGL(pupil_position_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, K, c, t, n, z, g_z, g_c, g_t, g_n);
+    const int herr = (int)hipGetLastError();
+    if (herr) return hip_fail(herr, "pupil_position_kernel launch");
     return TL_OK;
 }
 
