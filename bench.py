@@ -260,7 +260,7 @@ def main():
     also = {}
     if not a.no_also and a.workload == "cfg3" and a.log2_pupil is None:
         main_state = (args, meta, leaves, asph, n_per_field_total)
-        for wname in ("cfg3a", "cfg2"):
+        for wname in ("cfg3a", "cfg2", "cfg5"):
             args, meta2, _ = workload(wname, device, world, rank, None)
             leaves = [args[k] for k in LEAF_NAMES if k in args]
             asph = {k: args[k] for k in ("kappa", "poly") if k in args}
