@@ -184,3 +184,35 @@ def test_cabi_library_exports_every_declared_symbol():
     p.F, p.P, p.W, p.S = 3, 1 << 20, 3, 7
     assert dll.tl_workspace_bytes(ctypes.byref(p)) > 0
     assert ctypes.sizeof(_lib.tl_problem) == dll.tl_problem_size() == 192
+
+
+def test_gradient_free_conversions_are_memoised_safely():
+    """lens_modeling caches the padding of constant nd / v and their dispersion (an optimisation loop rebuilds
+    the same Lens every step).  The cache must notice new data at a recycled address, in-place updates of the
+    source, and writes into a cached result."""
+    import gc
+    from torchoptics_amd import lens_modeling as lm
+    st = lm.Structure(stop_idx=np.array([2]), sequence=np.array(["GAAGA"]), default_device="cpu")
+    c, t = torch.zeros(5), torch.ones(5)
+
+    def indices(nd_vals, v_vals):
+        lens = lm.Lens(st, c, t, torch.tensor(nd_vals), torch.tensor(v_vals))
+        return lens.get_refractive_indices((656.3, 587.6, 486.1)).clone()
+
+    a = indices([1.5, 1.6], [60.0, 40.0])
+    gc.collect()                                        # the first tensors are gone: their addresses may be reused
+    b = indices([1.7, 1.8], [30.0, 50.0])
+    assert not torch.equal(a, b) and abs(b[0, 0, 1].item() - 1.7) < 1e-4 and abs(a[0, 0, 1].item() - 1.5) < 1e-4
+    nd, v = torch.tensor([1.5, 1.6]), torch.tensor([60.0, 40.0])
+    n1 = lm.Lens(st, c, t, nd, v).get_refractive_indices((587.6,))
+    n2 = lm.Lens(st, c, t, nd, v).get_refractive_indices((587.6,))
+    assert n2.data_ptr() == n1.data_ptr() or torch.equal(n1, n2)            # served from the cache (or equal)
+    nd.mul_(1.01)                                                           # in-place update of the source
+    n3 = lm.Lens(st, c, t, nd, v).get_refractive_indices((587.6,))
+    assert abs(n3[0, 0, 0].item() - 1.515) < 1e-4
+    n3.zero_()                                                              # somebody scribbles on a cached result
+    n4 = lm.Lens(st, c, t, nd, v).get_refractive_indices((587.6,))
+    assert abs(n4[0, 0, 0].item() - 1.515) < 1e-4
+    nd_g = nd.clone().requires_grad_(True)                                  # with autograd: always fresh, with a graph
+    n5 = lm.Lens(st, c, t, nd_g, v).get_refractive_indices((587.6,))
+    assert n5.requires_grad

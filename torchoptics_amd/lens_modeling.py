@@ -181,23 +181,25 @@ class Specs:
 # Results of the last few gradient-free conversions (padding of constant nd / v, dispersion of constant
 # glasses): an optimisation loop re-builds the same Lens every step, and each of these is several tiny
 # launches whose host cost (~8 us each) is what bounds small workloads.  Keyed by storage, version counter,
-# shape and dtype, so an in-place update of the source invalidates the entry.
+# shape and dtype, so an in-place update of the source invalidates the entry (writes through `.data` do not
+# bump the version counter: they are the one way to defeat it, as they are for autograd itself).
 _memo = {}
 
 
-def _memo_key(tag, *tensors, extra=()):
-    return (tag, extra) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device) for t in tensors)
-
-
-def _memoised(key, tensors, fn):
-    if any(t.requires_grad for t in tensors):
+def _memoised(tag, extra, key_tensors, grad_tensors, fn):
+    """fn() cached on (tag, extra, identity of key_tensors); recomputed whenever one of grad_tensors takes part
+    in autograd (the result then carries a graph and must be fresh)."""
+    if any(t.requires_grad for t in grad_tensors):
         return fn()
+    key = (tag, extra) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device) for t in key_tensors)
     hit = _memo.get(key)
     if hit is None or hit[0]._version != hit[1]:         # never computed, or somebody wrote into the cached result
         if len(_memo) > 64:
             _memo.clear()
         out = fn()
-        hit = _memo[key] = (out, out._version)
+        # the entry keeps its key tensors alive: while it exists their storage cannot be freed and handed to
+        # another tensor, so an equal (address, version, shape) key always means the same data
+        hit = _memo[key] = (out, out._version, tuple(key_tensors))
     return hit[0]
 
 
@@ -211,7 +213,7 @@ def _pad_from_flat(flat: torch.Tensor, mask_t: torch.Tensor, fill: float, idx: t
     def pad():
         base = torch.full((mask_t.numel(), *tail), fill, dtype=flat.dtype, device=mask_t.device)
         return base.index_copy(0, idx, flat).reshape(*mask_t.shape, *tail)
-    return _memoised(_memo_key("pad", flat, idx, extra=(fill if fill == fill else "nan", tuple(mask_t.shape))), (flat,), pad)
+    return _memoised("pad", (fill if fill == fill else "nan", tuple(mask_t.shape)), (flat, idx), (flat,), pad)
 
 
 def _take(padded: torch.Tensor, width: int, idx: torch.Tensor) -> torch.Tensor:
@@ -220,7 +222,7 @@ def _take(padded: torch.Tensor, width: int, idx: torch.Tensor) -> torch.Tensor:
     flat = cut.reshape(cut.shape[0] * width, *cut.shape[2:])
     if idx.numel() == flat.shape[0]:             # every entry is kept: a view
         return flat
-    return _memoised(_memo_key("take", padded, idx, extra=(width,)), (padded,), lambda: flat.index_select(0, idx))
+    return _memoised("take", (width,), (padded, idx), (padded,), lambda: flat.index_select(0, idx))
 
 
 @dataclass
@@ -350,8 +352,8 @@ class Lens:
             n = torch.where(self.structure.mask_G_torch[..., None], n, torch.ones_like(n))
             dispersive = (self.v != 0)[..., None]
             return torch.where(dispersive, n, self.nd[..., None].expand_as(n))
-        key = _memo_key("n", self.nd, self.v, self.structure.mask_G_torch, extra=tuple(float(w) for w in wavelengths))
-        return _memoised(key, (self.nd, self.v), dispersion)
+        return _memoised("n", tuple(float(w) for w in wavelengths), (self.nd, self.v, self.structure.mask_G_torch),
+                         (self.nd, self.v), dispersion)
 
     # ---- first-order properties (paraxial.py) ----------------------------------
     @property
