@@ -2,7 +2,7 @@
 """
 bench.py -- rays/s of the sequential ray-trace hot path, forward + backward, on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5] [--mode strict|fast]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg3a|cfg2|cfg5] [--mode strict|fast]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
