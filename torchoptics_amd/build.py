@@ -28,7 +28,11 @@ COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno
           # MemorySSA walk limit (100) the AMDGPU back end gives up proving that the wave-uniform loads of
           # the prescription (c, t, mu, kappa, poly) are never clobbered and emits them as VECTOR loads
           # (180 global_load per ray in trace_bwd_kernel<12,asph>) instead of scalar s_load.
-          "-mllvm", "-memssa-check-limit=4000"]
+          "-mllvm", "-memssa-check-limit=4000",
+          # Long dependent FMA chains with independent side computations (the rounding fix-ups of sqrt, the
+          # adjoint's parallel branches): the ILP-driven iterative scheduler interleaves them better than the
+          # default (same instructions, bit-identical results; measured -1.5 % forward, -4..6 % walk-back).
+          "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 # strict: no FMA contraction, HIP's default correctly rounded fp32 sqrt / divide
 # fast  : contraction on; the kernels call v_rcp / v_sqrt explicitly
 UNITS = {
