@@ -56,7 +56,9 @@ Plan plan_fwd(const tl_problem *p)
 
 Plan plan_bwd(const tl_problem *p)
 {
-    static const int target = env_int("TL_BWD_BLOCKS", 4096), rmax = env_int("TL_BWD_RMAX", 64);
+    // 8192 blocks = 4.6 rounds of the 1792 resident blocks (7 waves per SIMD): the partially filled last round
+    // weighs less than at 4096 (-2 % on the walk-back kernel, sweep in tools/ab_kernels.py with TL_BWD_BLOCKS)
+    static const int target = env_int("TL_BWD_BLOCKS", 8192), rmax = env_int("TL_BWD_RMAX", 64);
     return make_plan(p->P, p->F * p->W, target, rmax);
 }
 
