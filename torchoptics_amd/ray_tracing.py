@@ -11,14 +11,12 @@ Tensor dims, as in the reference: [lens (=1), field, pupil, wavelength(, surface
 """
 from __future__ import annotations
 
-import math
-from typing import Optional, Sequence
+from typing import Optional
 
 import numpy as np
 import torch
 
 from . import ops
-from .ops import TL_NMOM
 from .paraxial import (compute_last_curvature, compute_magnification, compute_pupil_position,  # noqa: F401
                        compute_pupil_radius, get_first_order, interface_propagation_abcd, reduce_abcd)
 
