@@ -396,3 +396,50 @@ def test_walk_back_non_finite_adjoint_falls_back_to_checkpoint_kernel(ta):
             ops.set_backward_algorithm("inverse")
     for a, b in zip(grads["inverse"], grads["checkpoint"]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_full_size_cfg3_properties(ta):
+    """BASELINE's cfg3 at full size (2^24 rays, 11 rows) through properties that need no oracle at that size:
+    (a) tracing the two halves of the pupil separately gives the same per-ray outputs bit for bit and moments that
+        add up to the full run's (this is also the multi-GPU sharding contract);
+    (b) two runs are bitwise identical (fixed-order reductions, no atomics), forward and gradients;
+    (c) the backward is linear in the upstream gradient of the moments: grad(a*g1 + b*g2) = a*grad(g1) + b*grad(g2)."""
+    import bench
+    args, meta, _ = bench.workload("cfg3", DEV, 1, 0, None)
+    P = meta["P_local"]
+    assert P == 1 << 24
+
+    def run(sl=slice(None), g_mom=None):
+        lv = {k: args[k].detach().clone().requires_grad_(True) for k in ("c", "t", "mu")}
+        x, y, cx, cy, ok, back = ta.trace_skew(args["x"][:, :, sl].contiguous(), args["y"][:, :, sl].contiguous(), args["z"],
+                                               args["cx"], args["cy"], lv["c"], lv["t"], lv["mu"], args["mask"])
+        mom = y._tl_spot[0]
+        if g_mom is None:
+            ta.compute_rms2d(x, y, ok).backward()
+        else:
+            mom.backward(g_mom)
+        return (x, y, cx, cy, ok, back), mom.detach().clone(), [lv[k].grad.clone() for k in ("c", "t", "mu")]
+
+    full, m_full, g_full = run()
+    again, m_again, g_again = run()
+    assert torch.equal(m_full, m_again) and all(torch.equal(a, b) for a, b in zip(g_full, g_again))          # (b)
+    assert all(torch.equal(a, b) for a, b in zip(full, again))
+    half = P // 2
+    lo, m_lo, _ = run(slice(0, half))
+    hi, m_hi, _ = run(slice(half, P))
+    for f_, l_, h_ in zip(full, lo, hi):                                                                  # (a)
+        assert torch.equal(f_[:, :, :half], l_) and torch.equal(f_[:, :, half:], h_)
+    assert torch.allclose(m_lo + m_hi, m_full, rtol=1e-12, atol=1e-9)
+    assert m_full[0, 3].item() == full[4].sum().item()                        # sum of ok = moment 3, exactly
+    gen = torch.Generator().manual_seed(5)
+    g1 = torch.zeros_like(m_full)
+    g2 = torch.zeros_like(m_full)
+    g1[:, :3] = torch.randn(m_full.shape[0], 3, generator=gen, dtype=torch.float64).to(DEV) * 1e-6
+    g2[:, :3] = torch.randn(m_full.shape[0], 3, generator=gen, dtype=torch.float64).to(DEV) * 1e-6
+    _, _, ga = run(g_mom=g1)
+    _, _, gb = run(g_mom=g2)
+    _, _, gc_ = run(g_mom=0.7 * g1 - 1.9 * g2)
+    for a, b, c_ in zip(ga, gb, gc_):                                                                     # (c)
+        want = 0.7 * a.double() - 1.9 * b.double()
+        scale = (0.7 * a.double().abs() + 1.9 * b.double().abs()).max().item()        # fp32 rounding of the terms
+        assert (c_.double() - want).abs().max().item() <= 2e-5 * scale
