@@ -75,3 +75,41 @@ def test_pupil_position_feeds_trace_rays_and_the_adam_step():
         grads[tag] = [c.grad.cpu().numpy(), t.grad.cpu().numpy()]
     for a, b in zip(grads["kernel"], grads["chain"]):
         assert rel_l2(a, b) < 5e-5           # the fp32 chain's own rounding of z moves the spot gradient at this level
+
+
+def test_pupil_position_c_abi_edges():
+    """K = 1 and K = TL_MAX_SURFACES rows against a float64 evaluation; bad arguments are refused, not launched."""
+    import ctypes as C
+    from torchoptics_amd import _lib
+    lib = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator().manual_seed(2)
+    for K in (1, _lib.TL_MAX_SURFACES):
+        c = ((torch.rand(K, generator=gen) - 0.5) * 0.05).to(DEV)
+        t = (torch.rand(K, generator=gen) * 3 + 0.5).to(DEV)
+        n = torch.cat((torch.ones(1), 1.0 + 0.7 * (torch.arange(K) % 2 == 0).float())).to(DEV)
+        z = torch.empty(1, device=DEV)
+        g = [torch.empty(K, device=DEV), torch.empty(K, device=DEV), torch.empty(K + 1, device=DEV)]
+        gz = torch.ones(1, device=DEV)
+        assert lib.tl_pupil_position(0, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), _lib.ptr(z), _lib.ptr(gz),
+                                     *[_lib.ptr(q) for q in g], st) == 0
+        cd, td, nd = (q.double().cpu().requires_grad_(True) for q in (c, t, n))
+        m = torch.eye(2, dtype=torch.float64)
+        for k in range(K):
+            r = nd[k] / nd[k + 1]
+            pw = cd[k] * (r - 1)
+            m = torch.stack((torch.stack((1 + pw * td[k], r * td[k])), torch.stack((pw, r)))) @ m
+        zz = m[0, 1] / m[0, 0]
+        zz.backward()
+        assert abs(z.item() - zz.item()) <= 2e-7 * abs(zz.item()) + 1e-9
+        for got, want in zip(g, (cd.grad, td.grad, nd.grad)):
+            assert rel_l2(got.cpu().numpy(), want.numpy()) < 1e-6
+    c = torch.zeros(4, device=DEV)
+    n = torch.ones(5, device=DEV)
+    z = torch.empty(1, device=DEV)
+    bad = [(0, c, c, n, z), (_lib.TL_MAX_SURFACES + 1, c, c, n, z), (4, None, c, n, z), (4, c, c, n, None)]
+    for K, a, b, nn, zz_ in bad:
+        rc = lib.tl_pupil_position(0, K, _lib.ptr(a), _lib.ptr(b), _lib.ptr(nn), _lib.ptr(zz_), None, None, None, None, st)
+        assert rc != 0 and lib.tl_last_error()
+    gz = torch.ones(1, device=DEV)
+    assert lib.tl_pupil_position(0, 4, _lib.ptr(c), _lib.ptr(c), _lib.ptr(n), _lib.ptr(z), _lib.ptr(gz), None, None, None, st) != 0
