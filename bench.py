@@ -10,23 +10,27 @@ N > 1 is launched by the driver as
 
 A "step" is one pass of the hot path over one resident batch of rays: trace_skew (fused forward
 kernel, per-ray outputs materialised as the reference API returns them, spot moments fused) ->
-compute_rms2d (closed form on the moments; one tiny all-reduce when N > 1) -> backward (recompute
-+ adjoint kernel) -> gradients of the loss w.r.t. the trace parameters (c, t, mu, z, cy) [-> one
+compute_rms2d (closed form on the moments; one tiny all-reduce when N > 1) -> backward (walk-back
+adjoint kernel) -> gradients of the loss w.r.t. the trace parameters (c, t, mu, z, cy) [-> one
 tiny all-reduce when N > 1].  The pupil coordinates are resident in HBM before the timed region.
+The K-step region is timed `--repeats` times (default 3) after ONE warm-up; `value` is the median.
 
 Workloads:
-  cfg3 (default): synthesized double Gauss, 11 rows (10 refracting surfaces + stop), F=1 field
-        (0.707), W=1 ('d'), circular pupil grid 4096 x 4096 = 2^24 rays PER GPU (weak scaling; at
-        N=8 this is cfg4's 2^27 rays).  This is the config BASELINE.json's metric ("M rays/s
-        through 10-surface lens; fwd+bwd") is quoted on.
+  cfg3 (default): the ALL-SPHERICAL variant of BASELINE configs[2]: synthesized double Gauss, 11 rows
+        (10 refracting surfaces + stop), F=1 field (0.707), W=1 ('d'), circular pupil grid 4096 x 4096 =
+        2^24 rays PER GPU (weak scaling; at N=8 this is cfg4's 2^27 rays).  The variant whose arithmetic the
+        reference pins (it has no aspheres): the config BASELINE.json's metric is quoted on.
   cfg3a: the same double Gauss with 2 aspheric rows (conic + a4, a6; Newton intersection) -- BASELINE
-        configs[2] as written; an extension beyond the reference (parity unpinned by it).
+        configs[2] as written; an extension beyond the reference (parity unpinned by it).  Reported with
+        its own roofline and gradient check under also.cfg3a of the default run.
   cfg2: Cooke triplet (7 rows), 1024 x 1024 pupil, 3 fields, W=1.
   cfg5: 20-row synthetic zoom, 5 fields x 3 wavelengths, 1024 x 1024 pupil.
+  sweep (default run, N=1): {2^20, 2^22, 2^24, 2^26} rays x {7, 11, 20} rows, F=W=1, fwd+bwd.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -39,7 +43,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 LEAF_NAMES = ("z", "cy", "c", "t", "mu", "kappa", "poly")   # differentiable arguments of trace_skew
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector (packed FMA)
+VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector (every issue slot an FMA)
+PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def parse():
@@ -47,37 +52,50 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=3, help="how often the K-step region is timed (value = median)")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg3a", "cfg2", "cfg5"])
     ap.add_argument("--mode", default=os.environ.get("TORCHOPTICS_AMD_MODE", "strict"), choices=["strict", "fast"])
     ap.add_argument("--log2-pupil", type=int, default=None, help="override log2 of pupil points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with one process: still build a 1-rank process group, so both collectives of the sharded "
+                         "path execute (RCCL on one GPU)")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the secondary measurement of the other arithmetic mode")
     ap.add_argument("--no-also", action="store_true", help="skip the extra workloads reported next to the main one")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the rays x rows sweep")
     ap.add_argument("--graph", action="store_true",
                     help="record one step (both kernels + reductions + closed form + autograd bookkeeping) into a HIP "
                          "graph and time replays of it instead of eager steps")
     ap.add_argument("--no-graph-child", action="store_true", help="skip the secondary HIP-graph measurement (child process)")
-    ap.add_argument("--cpu-log2-rays", type=int, default=20, help="log2 of the CPU-baseline sample (rays)")
+    ap.add_argument("--cpu-log2-rays", type=int, default=20, help="log2 of the gradient-check sample (rays)")
+    ap.add_argument("--cpu-full-log2-rays", type=int, default=24,
+                    help="log2 of the rays of the timed CPU baseline (chunked at 2^22 rays)")
     return ap.parse_args()
 
 
-def workload(name, device, world, rank, log2_pupil):
-    """Returns dict(lens args as leaves, pupil slice, meta)."""
-    import torchoptics_amd as ta
-    from torchoptics_amd import prescriptions as P, ray_tracing as rt
-    if name in ("cfg3", "cfg3a"):
-        lens, specs, leaves = P.double_gauss(device, aspheres=(name == "cfg3a"))
-        fields, wl, lp = (0.707,), ("d",), 24
-    elif name == "cfg2":
+# ------------------------------------------------------------------------------------------ workloads
+def build_lens(name, device):
+    from torchoptics_amd import prescriptions as P
+    if name in ("cfg3", "cfg3a", "dg11"):
+        return P.double_gauss(device, aspheres=(name == "cfg3a"))
+    if name in ("cfg2", "cooke7"):
         import yaml_free_lenses as L
-        lens, specs, leaves = L.build("cooke", device)
-        fields, wl, lp = (0., 0.707, 1.), ("d",), 20
-    else:
-        lens, specs, leaves = P.zoom20(device)
-        fields, wl, lp = tuple(np.linspace(0, 1, 5)), ("C", "d", "F"), 20
-    lp = log2_pupil if log2_pupil is not None else lp
+        return L.build("cooke", device)
+    return P.zoom20(device)
+
+
+def workload(name, device, world, rank, log2_pupil, fields=None, wl=None):
+    """Returns (trace_skew arguments as leaves, meta, extras) for this rank's pupil slice."""
+    import torchoptics_amd as ta
+    from torchoptics_amd import ray_tracing as rt
+    lens, specs, leaves = build_lens(name, device)
+    dflt = {"cfg3": ((0.707,), ("d",), 24), "cfg3a": ((0.707,), ("d",), 24), "cfg2": ((0., 0.707, 1.), ("d",), 20),
+            "cfg5": (tuple(np.linspace(0, 1, 5)), ("C", "d", "F"), 20)}.get(name, ((0.707,), ("d",), 24))
+    fields = fields or dflt[0]
+    wl = wl or dflt[1]
+    lp = log2_pupil if log2_pupil is not None else dflt[2]
     p_local = 1 << lp
     n_r = 1 << (lp // 2)
     n_theta_total = (p_local // n_r) * world            # weak scaling: the grid grows with N
@@ -90,35 +108,183 @@ def workload(name, device, world, rank, log2_pupil):
     for k in LEAF_NAMES:
         if k in args:
             args[k].requires_grad_(True)
+    n_asph = 0
+    if "kappa" in args:
+        n_asph = int(((args["kappa"].reshape(-1) != 0) | (args["poly"].reshape(-1, 4) != 0).any(dim=1)).sum().item())
     meta = dict(F=len(fields), W=len(wl), S=lens.c.shape[1], P_local=p_local, P_total=p_local * world,
-                lens=name, fields=list(map(float, fields)), wavelengths=list(wl))
+                lens=name, fields=list(map(float, fields)), wavelengths=list(wl), n_asph=n_asph,
+                n_r=n_r, n_theta=n_theta_total)
     return args, meta, (tr, specs, lens, leaves, xy)
 
 
+class Job:
+    """One workload resident on this rank's GPU and the step that is timed."""
+
+    def __init__(self, name, device, world, rank, group, log2_pupil=None, fields=None, wl=None):
+        self.args, self.meta, self.extra = workload(name, device, world, rank, log2_pupil, fields, wl)
+        self.name, self.group, self.world = name, group, world
+        self.leaves = [self.args[k] for k in LEAF_NAMES if k in self.args]
+        self.asph = {k: self.args[k] for k in ("kappa", "poly") if k in self.args}
+        self.n_per_field_total = self.meta["P_total"] * self.meta["W"]
+        self.rays_local = self.meta["F"] * self.meta["W"] * self.meta["P_local"]
+        self.rays_total = self.rays_local * world
+
+    def step(self):
+        import torchoptics_amd as ta
+        from torchoptics_amd import dist as tl_dist
+        a = self.args
+        for p in self.leaves:
+            p.grad = None
+        x, y, cx, cy, ok, back = ta.trace_skew(a["x"], a["y"], a["z"], a["cx"], a["cy"], a["c"], a["t"], a["mu"],
+                                               a["mask"], **self.asph)
+        rms = ta.compute_rms2d(x, y, ok, group=self.group, n_per_field=self.n_per_field_total)
+        rms.backward()
+        if self.group is not None:
+            tl_dist.all_reduce_grads(self.leaves, self.group)
+        return rms.detach()
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress line on stderr (the JSON line on stdout stays the only stdout output)."""
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def sync(group):
+    if group is not None:
+        torch.distributed.barrier(group)
+    torch.cuda.synchronize()
+
+
+def timed(job, mode, steps, warmup, repeats, graph, backend, device):
+    """W untimed warm-up steps, then `repeats` regions of exactly K steps, each between barrier+synchronize;
+    every region's time is the max over ranks.  Returns (list of seconds, kernel ms dict, rms)."""
+    from torchoptics_amd import ops
+    ops.set_default_mode(mode)
+    group = job.group
+    times, km = [], {}
+    if graph:
+        # warm up ON the capture stream: every autograd node and allocation of the step is created there
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            for _ in range(max(warmup, 3)):
+                r = job.step()
+        torch.cuda.current_stream().wait_stream(cap)
+        for p_ in job.leaves:
+            p_.grad = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            r = job.step()
+        for _ in range(warmup):
+            g.replay()
+        for _ in range(repeats):
+            sync(group)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g.replay()
+            sync(group)
+            times.append(time.perf_counter() - t0)
+    else:
+        for _ in range(warmup):
+            r = job.step()
+        for _ in range(repeats):
+            sync(group)
+            ops.enable_timing(True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r = job.step()
+            sync(group)
+            times.append(time.perf_counter() - t0)
+            k = ops.timing_ms()
+            ops.enable_timing(False)
+            for key, v in k.items():
+                km.setdefault(key, []).append(v)
+        km = {key: (statistics.median(v) if all(q is not None for q in v) else None) for key, v in km.items()}
+    if group is not None:
+        tmax = torch.tensor(times, dtype=torch.float64, device="cpu" if backend == "gloo" else device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX, group=group)
+        times = tmax.tolist()
+    return times, km, r
+
+
+# ------------------------------------------------------------------------------------------ roofline
 def pmc_traffic(workload_name, mode, kernel, meta):
     """HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
     gfx950 FETCH correction applied) for this workload at its default size; None if not profiled."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            d = json.load(f)
-        if meta["P_local"] != (1 << 24):
-            return None
-        return d[workload_name][mode][kernel]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        return None
+    if meta["P_local"] != (1 << 24):
+        return None, None
+    for fn in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                d = json.load(f)
+            return d[workload_name][mode][kernel]["hbm_bytes"], fn
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
-def flops_per_ray(S):
+def flops_per_ray(S, n_asph=0):
     """fp32 arithmetic operations per ray as written in csrc/tl_kernels.inc (mul, add/sub, sqrt, div,
-    rcp each count 1; compares, selects, negations not counted; counted by hand):
-    step_fwd 54 per surface (+5 image plane); step_bwd 49 recompute + 99 adjoint per surface; the
-    backward kernel runs step_fwd once more to reach the image plane (+30 seeds/entrance)."""
-    fwd = 54 * S + 5
-    bwd = fwd + (49 + 99) * S + 30          # checkpoint kernel: forward sweep + recompute + adjoint
-    bwd_inv = (51 + 17 + 99) * S + 40       # walk-back kernel: inverse refraction + intersection, partial recompute, adjoint
-    return fwd, bwd, bwd_inv
+    rcp, rsq each count 1, an FMA-able pair counts 2; compares, selects, negations, abs not counted; counted by
+    hand from the source, see DESIGN.md "Flop counts").
+      spherical row : step_fwd 54 | walk-back (inverse refraction + intersection 51, partial recompute 17,
+                      adjoint 99) = 167 | checkpoint backward = forward sweep 54 + recompute 49 + adjoint 99
+      aspheric row  : step_fwd_asph = sphere guess 27 + 2 Newton steps x 53 (the minimum: one step, plus the one
+                      after the convergence vote) + converged sag / acceptance test 43 + vector Snell 36 = 212;
+                      walk-back = aspheric normal + inverse vector Snell 55, Newton hit on that row from the next one
+                      27 + 2 x 53 + 6 = 139, step_bwd_asph 238 + coefficient wave sums 14 = 446;
+                      checkpoint backward = forward sweep 212 + step_bwd_asph 252
+    The Newton step count is data dependent; 2 per row is the floor, so aspheric flop rates are LOWER bounds."""
+    sph = S - n_asph
+    fwd = 54 * sph + 212 * n_asph + 5
+    bwd_ck = fwd + (49 + 99) * sph + 252 * n_asph + 30
+    bwd_inv = 167 * sph + 446 * n_asph + 40
+    return fwd, bwd_ck, bwd_inv
 
 
+def roofline_of(job, kern_ms, mode):
+    """roofline / roofline_valu / per-kernel table of one measured workload (event-timed launches)."""
+    from torchoptics_amd import ops
+    meta = job.meta
+    fw = meta["F"] * meta["W"]
+    inv = ops.get_backward_algorithm() == "inverse"
+    # algorithmic bytes per ray (DESIGN.md "bytes per unit"): forward writes x,y,cx,cy,ok,back and reads x_in,y_in;
+    # the walk-back backward reads x_in,y_in and the forward's x,y,cx,cy,ok; the checkpoint backward only x_in,y_in
+    b_fwd, b_bwd = 18.0 + 8.0 / fw, (17.0 if inv else 0.0) + 8.0 / fw
+    f_fwd, f_ck, f_inv = flops_per_ray(meta["S"], meta["n_asph"])
+    f_bwd = f_inv if inv else f_ck
+    bwd_name = ("trace_bwd_inv_kernel<asph>" if meta["n_asph"] else "trace_bwd_inv_kernel") if inv else "trace_bwd_kernel"
+    kernels = {}
+    for key, bpr, fpr in (("fwd", b_fwd, f_fwd), ("bwd", b_bwd, f_bwd)):
+        ms = kern_ms.get(key)
+        if ms:
+            kernels[key] = dict(ms=ms, rays_per_s=job.rays_local / ms * 1e3, hbm_GBs=job.rays_local * bpr / ms / 1e6,
+                                valu_TFLOPs=job.rays_local * fpr / ms / 1e9, bytes_per_ray=bpr, flops_per_ray=fpr)
+    dom = kernels.get("bwd")
+    if not dom:
+        return None, None, kernels, b_fwd + b_bwd
+    traffic, src = pmc_traffic(job.name, mode, "bwd", meta)
+    roofline = dict(kernel=bwd_name, bound="hbm", achieved=dom["hbm_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=dom["hbm_GBs"] / HBM_PEAK_GBS, traffic=traffic, traffic_source=src,
+                    launch_ms=dom["ms"], algorithmic_bytes_per_launch=job.rays_local * b_bwd,
+                    note="per-ray FMA kernel: the binding limit is the FP32 vector ALU, see roofline_valu; traffic = "
+                         "HBM bytes per launch from the committed rocprofv3 PMC passes, null for sizes not profiled")
+    valu = dict(kernel=bwd_name, bound="valu_fp32", achieved=dom["valu_TFLOPs"], peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=dom["valu_TFLOPs"] / VALU_PEAK_TFLOPS,
+                note="aspheric rows counted at the 2-Newton-step floor: a lower bound" if meta["n_asph"] else None)
+    return roofline, valu, kernels, b_fwd + b_bwd
+
+
+def summarize(job, times, steps):
+    med = statistics.median(times)
+    return dict(value=job.rays_total * steps / med / 1e6, unit="M rays/s", ms_per_step=med / steps * 1e3,
+                repeats_ms_per_step=[t / steps * 1e3 for t in times])
+
+
+# ------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,194 +298,134 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
-    group = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(device))
-        else:
-            dist.init_process_group("gloo")
-        group = dist.group.WORLD
 
-    import torchoptics_amd as ta
     from torchoptics_amd import _lib, ops, dist as tl_dist
+    group = tl_dist.init_group(device, a.backend, force=a.force_dist)
+    n_seen = tl_dist.ranks_seen(group, "cpu" if a.backend == "gloo" else device) if group is not None else 1
     _lib.lib()      # fail loudly when the HIP library is missing
     ops.set_default_mode(a.mode)
 
-    args, meta, extra = workload(a.workload, device, world, rank, a.log2_pupil)
-    leaves = [args[k] for k in LEAF_NAMES if k in args]
-    asph = {k: args[k] for k in ("kappa", "poly") if k in args}
-    n_per_field_total = meta["P_total"] * meta["W"]
+    log(f"workload {a.workload}, mode {a.mode}, world {world}, graph {a.graph}")
+    job = Job(a.workload, device, world, rank, group, a.log2_pupil)
+    meta = job.meta
+    times, kern_ms, rms = timed(job, a.mode, a.steps, a.warmup, a.repeats, a.graph, a.backend, device)
+    head = summarize(job, times, a.steps)
+    roofline, roofline_valu, kernels, step_bpr = roofline_of(job, kern_ms, a.mode)
+    inv = ops.get_backward_algorithm() == "inverse"
+    solo = world == 1
 
-    def step():
-        for p in leaves:
-            p.grad = None
-        x, y, cx, cy, ok, back = ta.trace_skew(args["x"], args["y"], args["z"], args["cx"], args["cy"], args["c"],
-                                               args["t"], args["mu"], args["mask"], **asph)
-        rms = ta.compute_rms2d(x, y, ok, group=group, n_per_field=n_per_field_total)
-        rms.backward()
-        if group is not None:
-            tl_dist.all_reduce_grads(leaves, group)
-        return rms
-
-    def sync():
-        if group is not None:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    def timed(mode):
-        """W untimed warm-up steps, then exactly K steps between barrier+synchronize; max over ranks."""
-        ops.set_default_mode(mode)
-        if a.graph:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(max(a.warmup, 3)):
-                    r = step()
-            torch.cuda.current_stream().wait_stream(side)
-            for p_ in leaves:
-                p_.grad = None
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                r = step()
-            for _ in range(a.warmup):
-                g.replay()
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                g.replay()
-            sync()
-            el, km = time.perf_counter() - t0, {}
-        else:
-            for _ in range(a.warmup):
-                r = step()
-            sync()
-            ops.enable_timing(True)
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                r = step()
-            sync()
-            el = time.perf_counter() - t0
-            km = ops.timing_ms()
-            ops.enable_timing(False)
-        if group is not None:
-            tmax = torch.tensor([el], dtype=torch.float64, device="cpu" if a.backend == "gloo" else device)
-            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-            el = tmax.item()
-        return el, km, r
-
-    dt, kern_ms, rms = timed(a.mode)
-
-    rays_local = meta["F"] * meta["W"] * meta["P_local"]
-    rays_total = rays_local * world
-    ms_per_step = dt / a.steps * 1e3
-    value = rays_total * a.steps / dt / 1e6
-
-    # ---- roofline of the dominant kernel (trace_bwd_kernel), per launch, from live event timing
-    fw = meta["F"] * meta["W"]
-    from torchoptics_amd import ops as _ops
-    inv = _ops.get_backward_algorithm() == "inverse"       # aspheric rows are walked back too
-    # algorithmic bytes per ray (DESIGN.md "bytes per unit"): forward writes x,y,cx,cy,ok,back and reads x_in,y_in;
-    # the walk-back backward reads x_in,y_in and the forward's x,y,cx,cy,ok; the checkpoint backward only x_in,y_in
-    b_fwd, b_bwd = 18.0 + 8.0 / fw, (17.0 if inv else 0.0) + 8.0 / fw
-    f_fwd, f_ck, f_inv = flops_per_ray(meta["S"])     # counted for spherical rows; aspheric rows cost more (not counted)
-    f_bwd = f_inv if inv else f_ck
-    bwd_kernel_name = "trace_bwd_inv_kernel" if inv else "trace_bwd_kernel"
-    kernels = {}
-    for key, bpr, fpr in (("fwd", b_fwd, f_fwd), ("bwd", b_bwd, f_bwd)):
-        ms = kern_ms.get(key)
-        if ms:
-            kernels[key] = dict(ms=ms, rays_per_s=rays_local / ms * 1e3, hbm_GBs=rays_local * bpr / ms / 1e6,
-                                valu_TFLOPs=rays_local * fpr / ms / 1e9, bytes_per_ray=bpr, flops_per_ray=fpr)
-    dom = kernels.get("bwd")
-    roofline = None
-    if dom:
-        roofline = dict(kernel=bwd_kernel_name, bound="hbm", achieved=dom["hbm_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=dom["hbm_GBs"] / HBM_PEAK_GBS, traffic=pmc_traffic(a.workload, a.mode, "bwd", meta),
-                        launch_ms=dom["ms"], algorithmic_bytes_per_launch=rays_local * b_bwd,
-                        note="per-ray FMA kernel: the binding limit is the FP32 vector ALU, see roofline_valu; "
-                             "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes "
-                             "(profiles/r01_pmc_traffic.json), null for workloads not profiled")
-    roofline_valu = None
-    if dom:
-        roofline_valu = dict(kernel=bwd_kernel_name, bound="valu_fp32", achieved=dom["valu_TFLOPs"],
-                             peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=dom["valu_TFLOPs"] / VALU_PEAK_TFLOPS)
-    # whole-step algorithmic HBM rate (fwd + bwd bytes at the API boundary, SURVEY 8d headline)
-    step_bytes = rays_total * (b_fwd + b_bwd)
-
+    log(f"main: {head['value']:.0f} M rays/s")
     other = None
     if not a.no_other_mode:
         om = "fast" if a.mode == "strict" else "strict"
-        odt, okm, orms = timed(om)
-        other = dict(arith_mode=om, value=rays_total * a.steps / odt / 1e6, unit="M rays/s", ms_per_step=odt / a.steps * 1e3,
-                     fwd_kernel_ms=okm.get("fwd"), bwd_kernel_ms=okm.get("bwd"), rms=float(orms.item()))
+        ot, okm, orms = timed(job, om, a.steps, a.warmup, a.repeats, a.graph, a.backend, device)
+        other = dict(arith_mode=om, **summarize(job, ot, a.steps), fwd_kernel_ms=okm.get("fwd"),
+                     bwd_kernel_ms=okm.get("bwd"), rms=float(orms.item()))
         ops.set_default_mode(a.mode)
 
-    # secondary workloads, same protocol (W warm-up + K timed steps), reported under "also"
+    # secondary workloads, same protocol, reported under "also" (N = 1 only: they are not part of the scaling run)
     also = {}
-    if not a.no_also and a.workload == "cfg3" and a.log2_pupil is None:
-        main_state = (args, meta, leaves, asph, n_per_field_total)
+    if solo and not a.no_also and a.workload == "cfg3" and a.log2_pupil is None:
         for wname in ("cfg3a", "cfg2", "cfg5"):
-            args, meta2, _ = workload(wname, device, world, rank, None)
-            leaves = [args[k] for k in LEAF_NAMES if k in args]
-            asph = {k: args[k] for k in ("kappa", "poly") if k in args}
-            n_per_field_total = meta2["P_total"] * meta2["W"]
-            adt, akm, arms = timed(a.mode)
-            nr = meta2["F"] * meta2["W"] * meta2["P_local"] * world
-            also[wname] = dict(value=nr * a.steps / adt / 1e6, unit="M rays/s", ms_per_step=adt / a.steps * 1e3,
-                               fwd_kernel_ms=akm.get("fwd"), bwd_kernel_ms=akm.get("bwd"), rays=nr, rows=meta2["S"],
-                               F=meta2["F"], W=meta2["W"], rms=float(arms.item()), arith_mode=a.mode)
-            if akm.get("fwd") and akm.get("bwd"):
-                # small workloads are bound by the eager Python/autograd chain (~0.25-0.4 ms of host time per
-                # step, box dependent), not by the GPU: also quote what the two trace kernels alone sustain
-                also[wname]["trace_kernels_only_value"] = nr / (akm["fwd"] + akm["bwd"]) / 1e3
-        args, meta, leaves, asph, n_per_field_total = main_state
+            log(f"also: {wname}")
+            j2 = Job(wname, device, world, rank, group)
+            t2, km2, r2 = timed(j2, a.mode, a.steps, a.warmup, a.repeats, a.graph, a.backend, device)
+            e = dict(**summarize(j2, t2, a.steps), fwd_kernel_ms=km2.get("fwd"), bwd_kernel_ms=km2.get("bwd"),
+                     rays=j2.rays_total, rows=j2.meta["S"], F=j2.meta["F"], W=j2.meta["W"], rms=float(r2.item()),
+                     arith_mode=a.mode, hip_graph=bool(a.graph))
+            if km2.get("fwd") and km2.get("bwd"):
+                # small workloads are bound by the eager Python/autograd chain, not by the GPU: what the two trace
+                # kernels alone sustain, and (hip_graph_value, from the graph child) what a recorded step reaches
+                e["trace_kernels_only_value"] = j2.rays_total / (km2["fwd"] + km2["bwd"]) / 1e3
+            if wname == "cfg3a" and not a.graph:
+                # BASELINE configs[2] as written: the full evidence of a headline line
+                rf, rv, kk, _ = roofline_of(j2, km2, a.mode)
+                e.update(roofline=rf, roofline_valu=rv, kernels=kk,
+                         workload="cfg3a: double Gauss with 2 aspheric rows (BASELINE configs[2] as written), S=11 rows, "
+                                  "F=1 W=1 P=2^24, circular grid, loss=compute_rms2d, fwd+bwd")
+                if not a.no_cpu_baseline:
+                    log("also: cfg3a gradient check against the oracle (CPU)")
+                    _, e["grad_rel_err_vs_pytorch_autograd"] = cpu_leg(j2.args, j2.meta, min(a.cpu_log2_rays, 18), a.mode,
+                                                                       time_it=False)
+            also[wname] = e
+            del j2
+            torch.cuda.empty_cache()
+
+    # north_star sweep: 1-64 M rays x 7 / 11 / 20 rows, one field, one wavelength, fwd+bwd
+    sweep = None
+    if solo and not a.no_sweep and not a.graph and a.workload == "cfg3" and a.log2_pupil is None:
+        sweep = []
+        for lens_name, rows in (("cooke7", 7), ("dg11", 11), ("zoom20", 20)):
+            log(f"sweep: {rows} rows")
+            for lp in (20, 22, 24, 26):
+                j3 = Job(lens_name, device, 1, 0, None, lp, fields=(0.707,), wl=("d",))
+                t3, km3, r3 = timed(j3, a.mode, max(5, a.steps // 2), 2, 1, False, a.backend, device)
+                s3 = summarize(j3, t3, max(5, a.steps // 2))
+                sweep.append(dict(rows=rows, rays=j3.rays_total, value=s3["value"], ms_per_step=s3["ms_per_step"],
+                                  fwd_kernel_ms=km3.get("fwd"), bwd_kernel_ms=km3.get("bwd"),
+                                  hbm_GBs=j3.rays_total * step_bpr_of(j3) / (s3["ms_per_step"] * 1e6)))
+                del j3
+                torch.cuda.empty_cache()
 
     # the same step replayed from a HIP graph, measured in a CHILD process (a capture failure of the
     # PyTorch/ROCm stack must not cost the main line); N = 1 only
     hip_graph = None
-    if world == 1 and not a.graph and not a.no_graph_child:
+    if solo and group is None and not a.graph and not a.no_graph_child:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--graph", "--steps", str(a.steps), "--warmup", str(a.warmup),
-               "--workload", a.workload, "--mode", a.mode, "--no-cpu-baseline", "--no-other-mode", "--no-also"]
+               "--repeats", str(a.repeats), "--workload", a.workload, "--mode", a.mode, "--no-cpu-baseline",
+               "--no-other-mode", "--no-sweep"]
+        if a.no_also:
+            cmd += ["--no-also"]
         if a.log2_pupil is not None:
             cmd += ["--log2-pupil", str(a.log2_pupil)]
+        log("HIP-graph child process")
         try:
-            cp = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+            cp = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
             if cp.returncode == 0 and line:
                 child = json.loads(line[-1])
                 hip_graph = dict(value=child["value"], unit="M rays/s", ms_per_step=child["ms_per_step"],
+                                 repeats_ms_per_step=child["repeats_ms_per_step"],
                                  note="the identical step recorded once into a HIP graph and replayed")
+                for wname, e in (child.get("also") or {}).items():
+                    if wname in also:
+                        also[wname]["hip_graph_value"] = e["value"]
+                        also[wname]["hip_graph_ms_per_step"] = e["ms_per_step"]
             else:
-                hip_graph = dict(error=f"child exited with {cp.returncode}")
+                hip_graph = dict(error=f"child exited with {cp.returncode}", stderr_tail=cp.stderr[-300:])
         except Exception as e:       # timeout or launch failure
             hip_graph = dict(error=repr(e))
 
-    cpu_baseline, grad_check = None, None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu_baseline, grad_check = cpu_leg(args, meta, a.cpu_log2_rays, a.mode)
+    cpu_baseline, grad_check, leaf_grads = None, None, None
+    if rank == 0 and solo and not a.no_cpu_baseline:
+        log("cpu baseline + gradient check")
+        cpu_baseline, grad_check = cpu_leg(job.args, meta, a.cpu_log2_rays, a.mode, full_log2=a.cpu_full_log2_rays)
+        log("leaf gradient check")
+        leaf_grads = leaf_grad_check(a.workload, device, a.mode)
+        log("done")
 
     if rank == 0:
         out = {
             "metric": "M rays/s through 10-surface lens; fwd+bwd; grad rel-err vs PyTorch autograd",
-            "value": value, "unit": "M rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": head["value"], "unit": "M rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {meta['lens']} S={meta['S']} rows, F={meta['F']} W={meta['W']} "
-                                   f"P={meta['P_local']} pupil points per GPU ({rays_local} rays/GPU, {rays_total} total), "
-                                   f"circular grid, loss=compute_rms2d, fwd+bwd",
+            "repeats": a.repeats, "repeats_ms_per_step": head["repeats_ms_per_step"], "n_ranks_seen": n_seen,
+            "config": {"workload": workload_label(a.workload, meta, job),
                        "arith_mode": a.mode, "backward_algorithm": "walk-back from the forward outputs (checkpoint kernel "
                        "as on-device fallback for ill-conditioned fans)" if inv else "checkpoint",
-                       "parallelism": f"pupil-sharded dp{world}", "rms": float(rms.item()),
-                       "hip_graph": bool(a.graph)},
+                       "parallelism": f"pupil-sharded dp{world}",
+                       "collectives": "none" if group is None else ("rccl" if a.backend == "nccl" else a.backend),
+                       "rms": float(rms.item()), "hip_graph": bool(a.graph)},
             "roofline": roofline, "roofline_valu": roofline_valu, "kernels": kernels,
-            "step_hbm_GBs": step_bytes / (dt / a.steps) / 1e9,
+            "step_hbm_GBs": job.rays_total * step_bpr / (head["ms_per_step"] * 1e6),
             "grad_rel_err_vs_pytorch_autograd": grad_check,
+            "leaf_grads": leaf_grads,
             "other_mode": other,
             "hip_graph_replay": hip_graph,
             "also": also,
+            "sweep": sweep,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
@@ -327,31 +433,77 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def cpu_leg(args, meta, log2_rays, mode):
-    """The oracle (CPU restatement of the reference, eager PyTorch fp32 + autograd) timed on this
-    box's host cores on a bounded sample of the same workload: the first 2^log2_rays/(F*W) pupil
-    points.  kind='port': the reference itself cannot travel to the GPU box.  The same sample is then
-    traced by the HIP path and the gradients are compared (norm-relative, per parameter group)."""
+def step_bpr_of(job):
+    fw = job.meta["F"] * job.meta["W"]
+    return (18.0 + 8.0 / fw) + (17.0 + 8.0 / fw)
+
+
+def workload_label(name, meta, job):
+    what = {"cfg3": "ALL-SPHERICAL variant of BASELINE configs[2] (double Gauss, no aspheric rows: the arithmetic the "
+                    "reference pins; the 2-asphere variant as written is under also.cfg3a)",
+            "cfg3a": "BASELINE configs[2] as written: double Gauss with 2 aspheric rows (extension, parity unpinned by the reference)",
+            "cfg2": "BASELINE configs[1]: Cooke triplet", "cfg5": "BASELINE configs[4] lens: 20-row zoom"}[name]
+    return (f"{name}: {what}; S={meta['S']} rows, F={meta['F']} W={meta['W']} P={meta['P_local']} pupil points per GPU "
+            f"({job.rays_local} rays/GPU, {job.rays_total} total), circular grid, loss=compute_rms2d, fwd+bwd")
+
+
+# ------------------------------------------------------------------------------------------ CPU legs (the checker)
+def _cpu_threads():
+    """(threads to use, description).  Every core this process may really run on: the scheduler affinity, cut to
+    the cgroup CPU quota when there is one -- a GPU box hands each job a share of its host cores, and an OpenMP
+    team larger than that share spends its time spinning at barriers (observed: a 1 s oracle call not finishing
+    in 7 minutes).  Without quota information the team is capped at 32 threads; TL_CPU_THREADS overrides."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, int(q / per + 0.5))
+        except (OSError, ValueError):
+            pass
+    if os.environ.get("TL_CPU_THREADS"):
+        n = max(1, min(aff, int(os.environ["TL_CPU_THREADS"])))
+        why = "TL_CPU_THREADS"
+    elif quota is not None:
+        n, why = min(aff, quota), f"cgroup cpu quota {quota}"
+    else:
+        n, why = min(aff, 32), "no cgroup quota visible: capped at 32"
+    return n, f"affinity {aff} cpus, {why}"
+
+
+def cpu_leg(args, meta, log2_rays, mode, time_it=True, full_log2=24):
+    """The oracle (CPU restatement of the reference, eager PyTorch fp32 + autograd) on this box's host cores.
+    kind='port': the reference itself cannot travel to the GPU box.
+      timing  (BASELINE.md section 3): every core the process may use, the first 2^full_log2 rays of the same
+              workload in chunks of <= 2^22 rays (autograd keeps ~300 B/ray/surface), fwd+bwd per chunk,
+              1 warm-up chunk + median of 3 passes;
+      gradient check: the first 2^log2_rays rays traced by the HIP path and by the oracle in fp32 (MKL sqrt and
+              correctly rounded sqrt) and fp64; norm-relative error per argument of trace_skew."""
     import torchoptics_amd as ta
     from oracle import trace_oracle as orc
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("TL_CPU_THREADS", "32"))))
+    cores, cores_why = _cpu_threads()
     torch.set_num_threads(cores)
-    print(f"[bench] cpu_baseline: oracle on {cores} threads ...", file=sys.stderr, flush=True)
     fw = meta["F"] * meta["W"]
     p = max(1, min(meta["P_local"], (1 << log2_rays) // fw))
     cpu = {k: v.detach().cpu() for k, v in args.items()}
-    cpu["x"], cpu["y"] = cpu["x"][:, :, :p].contiguous(), cpu["y"][:, :, :p].contiguous()
+    x_all, y_all = cpu["x"], cpu["y"]
     names = tuple(k for k in LEAF_NAMES if k in cpu)
     leaves = [cpu[k].requires_grad_(True) for k in names]
     is_asph = "kappa" in cpu
     kind = ((cpu["kappa"].reshape(-1) != 0) | (cpu["poly"].reshape(-1, 4) != 0).any(dim=1)).int().tolist() if is_asph else None
 
-    def one(dt=None, ieee=False):
-        src = cpu if dt is None else {k: (v.to(dt) if v.is_floating_point() else v) for k, v in cpu.items()}
+    def one(lo, hi, dt=None, ieee=False):
+        src = dict(cpu) if dt is None else {k: (v.to(dt) if v.is_floating_point() else v) for k, v in cpu.items()}
+        src["x"], src["y"] = x_all[:, :, lo:hi].to(dt or x_all.dtype), y_all[:, :, lo:hi].to(dt or y_all.dtype)
         lv = leaves if dt is None else [src[k].detach().requires_grad_(True) for k in names]
         if dt is not None:
             src.update(dict(zip(names, lv)))
@@ -366,18 +518,40 @@ def cpu_leg(args, meta, log2_rays, mode):
                                                     src["t"], src["mu"], src["mask"], ieee_sqrt=ieee)
         orc.compute_rms2d(x, y, ok).backward()
         return [q.grad.clone() for q in lv]
-    t0 = time.perf_counter()
-    one()                                   # warm-up (first touch is ~15x slower)
-    print(f"[bench] cpu_baseline warm-up {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
-    times = []
-    for _ in range(3):
+
+    base = None
+    if time_it:
+        log(f"cpu_baseline: oracle on {cores} threads ({cores_why})")
+        p_full = max(1, min(meta["P_local"], (1 << full_log2) // fw))
+        chunk = max(1, (1 << 22) // fw)
+        bounds = [(lo, min(lo + chunk, p_full)) for lo in range(0, p_full, chunk)]
         t0 = time.perf_counter()
-        g32 = one()
-        times.append(time.perf_counter() - t0)
-        print(f"[bench] cpu_baseline rep {times[-1]:.2f}s", file=sys.stderr, flush=True)
-    med = sorted(times)[1]
-    g64 = one(torch.float64)
-    g32i = one(None, ieee=True)
+        one(*bounds[0])                         # warm-up (first touch is ~15x slower)
+        log(f"cpu_baseline warm-up chunk {time.perf_counter() - t0:.1f}s")
+        passes = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for lo, hi in bounds:
+                one(lo, hi)
+            passes.append(time.perf_counter() - t0)
+            log(f"cpu_baseline pass {passes[-1]:.2f}s")
+            if sum(passes) > 45.0:              # bounded: never let the baseline dominate the run
+                break
+        med = statistics.median(passes)
+        try:
+            model = [ln.split(":")[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+        except Exception:
+            model = "unknown"
+        base = dict(value=p_full * fw / med / 1e6, unit="M rays/s", cores=cores, kind="port",
+                    sample=f"{p_full * fw} rays of the same workload in {len(bounds)} chunks of <= {chunk * fw} rays "
+                           f"(RMS loss and autograd backward per chunk), fwd+bwd, median of {len(passes)} passes after "
+                           f"a 1-chunk warm-up, torch threads={cores} ({cores_why}), cpu='{model}'")
+
+    log(f"gradient check: oracle fp32 / fp64 / fp32-ieee on {p * fw} rays, {cores} threads")
+    g32 = one(0, p)
+    g64 = one(0, p, torch.float64)
+    g32i = one(0, p, None, ieee=True)
+    log("gradient check: HIP path")
     # the same sample through the HIP path
     dev = args["x"].device
     gl = [args[k].detach().clone().requires_grad_(True) for k in names]
@@ -396,53 +570,126 @@ def cpu_leg(args, meta, log2_rays, mode):
                      vs_fp64_autograd=rel(q.grad.cpu(), r64), fp32_autograd_mkl_vs_ieee=rel(r32, r32i),
                      fp32_autograd_mkl_vs_fp64=rel(r32, r64))
     lens_groups = tuple(k for k in ("c", "t", "mu", "kappa", "poly") if k in gc)
+    launch = tuple(k for k in ("z", "cy") if k in gc)
+    mx = lambda key, ks: max(gc[k][key] for k in ks)      # noqa: E731
     grad_check = dict(sample_rays=p * fw, arith_mode=mode, per_group=gc,
-                      max_vs_fp32_autograd=max(gc[k]["vs_fp32_autograd_ieee_sqrt"] for k in lens_groups),
-                      max_vs_fp32_autograd_mkl_sqrt=max(gc[k]["vs_fp32_autograd_mkl_sqrt"] for k in lens_groups),
-                      max_vs_fp64_autograd=max(gc[k]["vs_fp64_autograd"] for k in lens_groups),
-                      pytorch_fp32_self_noise=max(gc[k]["fp32_autograd_mkl_vs_ieee"] for k in lens_groups),
-                      note="norm-relative error per parameter group, max over the lens parameters c, t, mu. "
-                           "PyTorch fp32 autograd = the CPU oracle (bit-exact with the reference on CPU). torch.sqrt on "
-                           "CPU (MKL) is up to 1 ulp off; 'ieee_sqrt' is the same autograd graph with a correctly "
-                           "rounded sqrt. pytorch_fp32_self_noise = how far those two PyTorch runs are from each "
-                           "other: the floor below which 'vs PyTorch autograd' is not defined for this lens")
-    # SURVEY 8(d), optional extra line: the same eager graph (oracle, ~86 elementwise launches per surface +
-    # autograd) on the MI355X itself, i.e. fused kernels vs eager PyTorch on identical silicon
-    eager_gpu = None
-    if not is_asph:
-        try:
-            pg = max(1, min(meta["P_local"], (1 << 22) // fw))      # 4 M rays: past the launch-bound regime,
-            gsrc = {k: (v.detach().to(dev)) for k, v in cpu.items()}     # ~13 GB of autograd-saved tensors at 11 rows
-            gsrc["x"], gsrc["y"] = args["x"][:, :, :pg].detach().contiguous(), args["y"][:, :, :pg].detach().contiguous()
-            glv = [gsrc[k].requires_grad_(True) for k in names]
-
-            def one_gpu():
-                for q in glv:
-                    q.grad = None
-                o = orc.trace_skew(gsrc["x"], gsrc["y"], gsrc["z"], gsrc["cx"], gsrc["cy"], gsrc["c"], gsrc["t"],
-                                   gsrc["mu"], gsrc["mask"])
-                orc.compute_rms2d(o[0], o[1], o[4]).backward()
-                torch.cuda.synchronize()
-            one_gpu()
-            tg = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                one_gpu()
-                tg.append(time.perf_counter() - t0)
-            eager_gpu = dict(value=pg * fw / sorted(tg)[1] / 1e6, unit="M rays/s",
-                             note=f"the oracle's eager PyTorch graph + autograd on this MI355X, {pg * fw} rays of the same workload")
-            del gsrc, glv
-            torch.cuda.empty_cache()
-        except Exception as e:                      # informational only: never fail the bench on it
-            eager_gpu = dict(value=None, note=f"not measured: {type(e).__name__}: {e}"[:200])
-    try:
-        model = [ln.split(":")[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
-    except Exception:
-        model = "unknown"
-    base = dict(value=p * fw / med / 1e6, unit="M rays/s", cores=cores, kind="port", eager_pytorch_on_gpu=eager_gpu,
-                sample=f"{p * fw} rays ({p} pupil points x {fw} field-wavelengths) of the same workload, fwd+bwd, "
-                       f"median of 3 after 1 warm-up, torch threads={cores}, cpu='{model}'")
+                      max_vs_fp32_autograd=mx("vs_fp32_autograd_ieee_sqrt", lens_groups),
+                      max_vs_fp32_autograd_mkl_sqrt=mx("vs_fp32_autograd_mkl_sqrt", lens_groups),
+                      max_vs_fp64_autograd=mx("vs_fp64_autograd", lens_groups),
+                      pytorch_fp32_self_noise=mx("fp32_autograd_mkl_vs_ieee", lens_groups),
+                      launch_conditions=dict(
+                          max_vs_fp32_autograd=mx("vs_fp32_autograd_ieee_sqrt", launch),
+                          max_vs_fp64_autograd=mx("vs_fp64_autograd", launch),
+                          pytorch_fp32_self_noise=mx("fp32_autograd_mkl_vs_ieee", launch),
+                          pytorch_fp32_vs_fp64=mx("fp32_autograd_mkl_vs_fp64", launch),
+                          note="d/dz and d/dcy are residuals ~1e-3 of their per-ray terms: PyTorch's own two fp32 runs "
+                               "differ by pytorch_fp32_self_noise here") if launch else None,
+                      note="norm-relative error per argument group of trace_skew; max_* over the lens parameters "
+                           "(c, t, mu[, kappa, poly]), the launch conditions z, cy are listed separately. PyTorch fp32 "
+                           "autograd = the CPU oracle (bit-exact with the reference on CPU). torch.sqrt on CPU (MKL) is up "
+                           "to 1 ulp off; 'ieee_sqrt' is the same autograd graph with a correctly rounded sqrt. "
+                           "pytorch_fp32_self_noise = how far those two PyTorch runs are from each other: the floor "
+                           "below which 'vs PyTorch autograd' is not defined for this lens")
+    if base is not None and not is_asph:
+        base["eager_pytorch_on_gpu"] = eager_on_gpu(orc, cpu, args, names, meta, dev)
     return base, grad_check
+
+
+def eager_on_gpu(orc, cpu, args, names, meta, dev):
+    """SURVEY 8(d), optional extra line: the same eager graph (oracle, ~86 elementwise launches per surface +
+    autograd) on the MI355X itself, i.e. fused kernels vs eager PyTorch on identical silicon."""
+    fw = meta["F"] * meta["W"]
+    try:
+        pg = max(1, min(meta["P_local"], (1 << 22) // fw))      # 4 M rays: past the launch-bound regime,
+        gsrc = {k: (v.detach().to(dev)) for k, v in cpu.items()}     # ~13 GB of autograd-saved tensors at 11 rows
+        gsrc["x"], gsrc["y"] = args["x"][:, :, :pg].detach().contiguous(), args["y"][:, :, :pg].detach().contiguous()
+        glv = [gsrc[k].requires_grad_(True) for k in names]
+
+        def one_gpu():
+            for q in glv:
+                q.grad = None
+            o = orc.trace_skew(gsrc["x"], gsrc["y"], gsrc["z"], gsrc["cx"], gsrc["cy"], gsrc["c"], gsrc["t"],
+                               gsrc["mu"], gsrc["mask"])
+            orc.compute_rms2d(o[0], o[1], o[4]).backward()
+            torch.cuda.synchronize()
+        one_gpu()
+        tg = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            one_gpu()
+            tg.append(time.perf_counter() - t0)
+        out = dict(value=pg * fw / sorted(tg)[1] / 1e6, unit="M rays/s",
+                   note=f"the oracle's eager PyTorch graph + autograd on this MI355X, {pg * fw} rays of the same workload")
+        del gsrc, glv
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:                      # informational only: never fail the bench on it
+        return dict(value=None, note=f"not measured: {type(e).__name__}: {e}"[:200])
+
+
+def leaf_grad_check(name, device, mode, log2_pupil=18):
+    """Gradients of the LEAVES (c, t, nd, v) through the whole RayTracer.trace_rays chain (dispersion, paraxial pupil
+    position, assembly, trace, RMS spot), HIP path vs the same chain on the CPU with the oracle's trace in fp32 and
+    fp64.  2^log2_pupil pupil points of the workload's fan."""
+    import torchoptics_amd as ta
+    from oracle import trace_oracle as orc
+    from torchoptics_amd import ray_tracing as rt
+    dflt = {"cfg3": ((0.707,), ("d",)), "cfg3a": ((0.707,), ("d",)), "cfg2": ((0., 0.707, 1.), ("d",)),
+            "cfg5": (tuple(np.linspace(0, 1, 5)), ("C", "d", "F"))}[name]
+    fields, wl = dflt
+    n_r = 1 << (log2_pupil // 2)
+    n_th = (1 << log2_pupil) // n_r
+    keys = ("c", "t", "nd", "v")
+
+    def gpu():
+        lens, specs, leaves = build_lens(name, device)
+        tr = ta.RayTracer(mode="circular", n_rays=(n_r, n_th), rel_fields=fields, wavelengths=wl, default_device=device,
+                          arith=mode)
+        x, y, cx, cy, ok, back = tr.trace_rays(specs, lens)
+        rt.compute_rms2d(x, y, ok).backward()
+        return {k: leaves[k].grad.detach().cpu() for k in keys}
+
+    def cpu(dtype, ieee):
+        from torchoptics_amd import lens_modeling as lm
+        lens0, specs0, leaves0 = build_lens(name, "cpu")
+        leaves = {k: leaves0[k].detach().to(dtype).requires_grad_(True) for k in leaves0}
+        lens = lm.Lens(lens0.structure, leaves["c"], leaves["t"], leaves["nd"], leaves["v"], leaves.get("kappa"),
+                       leaves.get("poly"))
+        specs = lm.Specs(lens0.structure, specs0.epd.to(dtype), specs0.hfov.to(dtype))
+        tr = ta.RayTracer(mode="circular", n_rays=(n_r, n_th), rel_fields=fields, wavelengths=wl, default_device="cpu")
+        a = tr.assemble(specs, lens)
+        a = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in a.items()}
+        if "kappa" in a:
+            kap, pol = a["kappa"].reshape(-1), a["poly"].reshape(-1, 4)
+            kind = ((kap != 0) | (pol != 0).any(dim=1)).int().tolist()
+            x, y, cx, cy, ok, back, _ = orc.trace_skew_general(a["x"], a["y"], a["z"], a["cx"], a["cy"], a["c"], a["t"],
+                                                               a["mu"], a["mask"], kap, pol, kind, ieee_sqrt=ieee)
+        else:
+            x, y, cx, cy, ok, back = orc.trace_skew(a["x"], a["y"], a["z"], a["cx"], a["cy"], a["c"], a["t"], a["mu"],
+                                                    a["mask"], ieee_sqrt=ieee)
+        orc.compute_rms2d(x, y, ok).backward()
+        return {k: leaves[k].grad.detach() for k in keys}
+
+    def rel(a, b):
+        return float(((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300)).item())
+    try:
+        g, r32, r32i, r64 = gpu(), cpu(torch.float32, False), cpu(torch.float32, True), cpu(torch.float64, False)
+        live = [k for k in keys if float(r64[k].norm()) > 0.0]       # e.g. d/dv is exactly 0 for a d-line-only fan
+        per = {k: dict(vs_fp32_chain_ieee_sqrt=rel(g[k], r32i[k]), vs_fp32_chain_mkl_sqrt=rel(g[k], r32[k]),
+                       vs_fp64_chain=rel(g[k], r64[k]), pytorch_fp32_vs_fp64=rel(r32[k], r64[k])) for k in live}
+        for k in keys:
+            if k not in live:
+                per[k] = dict(zero_gradient=True, abs_norm_hip=float(g[k].double().norm()))
+        vals = [per[k] for k in live]
+        return dict(sample_rays=len(fields) * len(wl) * (1 << log2_pupil), arith_mode=mode, per_leaf=per,
+                    max_vs_fp32_chain=max(v["vs_fp32_chain_ieee_sqrt"] for v in vals),
+                    max_vs_fp64_chain=max(v["vs_fp64_chain"] for v in vals),
+                    max_pytorch_fp32_vs_fp64=max(v["pytorch_fp32_vs_fp64"] for v in vals),
+                    note="d(rms)/d(c, t, nd, v) through RayTracer.trace_rays end to end: HIP path (kernels + tl_pupil_position "
+                         "+ autograd over the host chain) vs the package's host chain on CPU tensors with the oracle's "
+                         "trace_skew / compute_rms2d, in fp32 (both sqrt flavours) and fp64; norm-relative per leaf")
+    except Exception as e:                      # a checker problem must not cost the measurement
+        return dict(error=f"{type(e).__name__}: {e}"[:300])
 
 
 if __name__ == "__main__":

@@ -25,27 +25,33 @@ sys.path.insert(0, ROOT)
 
 
 def run(steps=100, lr=2e-4, log2_pupil=20, workload="zoom20", device="cuda:0", group=None, rank=0, world=1,
-        arith="strict", verbose=False, graph=False):
+        arith="strict", verbose=False, graph=False, aim=0, capturable=None):
     import torchoptics_amd as ta
     from torchoptics_amd import dist as tl_dist, prescriptions as P, ray_tracing as rt
     lens_fn = {"zoom20": P.zoom20, "double_gauss": P.double_gauss}[workload]
+    # The prescription builder returns a Lens whose padded c/t are VIEWS of the leaves: a piece of autograd
+    # graph (and with it the leaves' AccumulateGrad nodes, which remember the stream they were created on)
+    # that would stay alive across steps.  Keep only the structure, the specs and the bare leaves.
     lens0, specs, leaves = lens_fn(device)
+    structure, n_rows = lens0.structure, int(lens0.c.shape[1])
+    del lens0
     fields = tuple(np.linspace(0, 1, 5)) if workload == "zoom20" else (0., 0.707, 1.)
     wl = ("C", "d", "F")
     p_local = 1 << log2_pupil
     n_r = 1 << (log2_pupil // 2)
     n_theta = (p_local // n_r) * world
     tracer = ta.RayTracer(mode="circular", n_rays=(n_r, n_theta), rel_fields=fields, wavelengths=wl,
-                          default_device=device, arith=arith)
+                          default_device=device, arith=arith, n_ray_aiming_iter=aim)
     xy = rt.circle_index_range(n_r, n_theta, rank * p_local, (rank + 1) * p_local, device)
     params = [leaves["c"], leaves["t"]]
-    opt = torch.optim.Adam(params, lr=lr, capturable=graph)
+    nd, v = leaves["nd"].detach(), leaves["v"].detach()
+    opt = torch.optim.Adam(params, lr=lr, capturable=graph if capturable is None else capturable)
     n_per_field = p_local * world * len(wl)
     history = []
 
     def one_step():
         opt.zero_grad(set_to_none=True)
-        lens = ta.Lens(lens0.structure, leaves["c"], leaves["t"], leaves["nd"].detach(), leaves["v"].detach())
+        lens = ta.Lens(structure, leaves["c"], leaves["t"], nd, v)
         x, y, cx, cy, ok, back = tracer.trace_rays(specs, lens, xy=xy)
         loss = rt.compute_rms2d(x, y, ok, group=group, n_per_field=n_per_field)
         loss.backward()
@@ -54,15 +60,35 @@ def run(steps=100, lr=2e-4, log2_pupil=20, workload="zoom20", device="cuda:0", g
         opt.step()
         return loss.detach()
 
-    history.append(one_step())          # warm-up (allocations), also the initial loss
-    torch.cuda.synchronize()
     if graph:
-        raise NotImplementedError(
-            "whole-step HIP-graph capture is disabled: on PyTorch 2.10+rocm7.0 hipStreamEndCapture segfaults as soon "
-            "as the captured region holds an ordinary autograd backward of the host chain (reproduced with "
-            "(p.sum()*2 + q.pow(2).sum()).backward() alone).  The trace kernels themselves capture and replay "
-            "correctly, see tests/test_gpu_adam_loop.py::test_trace_kernels_capture_in_a_hip_graph.")
+        # Whole-step HIP graph: forward kernel, moments all-reduce, closed form, backward kernel, the host chain's
+        # autograd (dispersion, pupil position), gradient all-reduce and Adam are recorded once and replayed.
+        # Every autograd node the captured backward touches must live on the CAPTURE stream: the engine runs a
+        # leaf's AccumulateGrad on the stream that node was created on, and a node left over from a default-
+        # stream warm-up makes the engine synchronise the capturing stream with the legacy default stream --
+        # which hipStreamEndCapture on ROCm answers with a segfault (round-1 gpurun_out/graph_dbg.log).  So: warm
+        # up ON the capture stream, keep no graph alive between steps, capture on that same stream.
+        cap = torch.cuda.Stream(device)
+        cap.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(cap):
+            for _ in range(3):
+                history.append(one_step())     # warm-up: allocations, Adam state, workspace of this stream
+        torch.cuda.current_stream(device).wait_stream(cap)
+        torch.cuda.synchronize()
+        history = history[:1]                  # the initial loss; the other warm-up steps are not reported
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            static_loss = one_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            g.replay()
+            history.append(static_loss.clone())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     else:
+        history.append(one_step())          # warm-up (allocations), also the initial loss
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
             history.append(one_step())
@@ -70,7 +96,7 @@ def run(steps=100, lr=2e-4, log2_pupil=20, workload="zoom20", device="cuda:0", g
         dt = time.perf_counter() - t0
     losses = torch.stack(history).cpu().tolist()
     rays = len(fields) * len(wl) * p_local * world
-    out = dict(workload=workload, rows=int(lens0.c.shape[1]), fields=len(fields), wavelengths=len(wl), rays_per_step=rays,
+    out = dict(workload=workload, rows=n_rows, fields=len(fields), wavelengths=len(wl), rays_per_step=rays,
                n_gpus=world, steps=steps, steps_per_s=steps / dt, M_rays_per_s=rays * steps / dt / 1e6,
                loss_initial=losses[0], loss_final=losses[-1], arith_mode=arith, hip_graph=bool(graph))
     if verbose and rank == 0:
@@ -86,21 +112,18 @@ def main():
     ap.add_argument("--workload", default="zoom20", choices=["zoom20", "double_gauss"])
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
-    ap.add_argument("--graph", action="store_true", help="(disabled, see run()) capture the whole step in a HIP graph")
+    ap.add_argument("--graph", action="store_true", help="record the whole optimisation step into a HIP graph and replay it")
+    ap.add_argument("--capturable", action="store_true", help="eager loop with Adam(capturable=True): the arithmetic of the graph path")
+    ap.add_argument("--aim", type=int, default=0, help="n_ray_aiming_iter (the reference's real caller uses 1)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise a 1-rank nccl (RCCL) group even when WORLD_SIZE=1")
     a = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    group = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-        else:
-            dist.init_process_group("gloo")
-        group = dist.group.WORLD
-    run(a.steps, a.lr, a.log2_pupil, a.workload, f"cuda:{local}", group, rank, world, a.mode, verbose=True, graph=a.graph)
+    from torchoptics_amd import dist as tl_dist
+    group = tl_dist.init_group(f"cuda:{local}", a.backend, force=a.force_dist)
+    run(a.steps, a.lr, a.log2_pupil, a.workload, f"cuda:{local}", group, rank, world, a.mode, verbose=True, graph=a.graph, aim=a.aim,
+        capturable=True if a.capturable else None)
     if group is not None:
         torch.distributed.destroy_process_group()
 

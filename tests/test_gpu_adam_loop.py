@@ -62,3 +62,32 @@ def test_trace_kernels_capture_in_a_hip_graph():
     assert static_loss.item() == eager
     for i, ref in zip((5, 6, 7), eager_g):
         assert torch.equal(ins[i].grad, ref)
+
+
+def _adam_child(*flags):
+    import json
+    import subprocess
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "adam_loop.py"), "--log2-pupil", "12", *flags],
+                        capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert cp.returncode == 0, f"adam_loop {flags} exited with {cp.returncode}\n{cp.stderr[-3000:]}"
+    return json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_whole_adam_step_replays_from_a_hip_graph():
+    """The WHOLE optimisation step -- Lens assembly, dispersion, paraxial pupil position, both trace kernels, the
+    RMS closed form, autograd over the host chain and Adam -- recorded once and replayed gives the eager loop's
+    numbers.  (Round 1 crashed in hipStreamEndCapture here: the warm-up had run on the default stream and the
+    leaves' AccumulateGrad nodes, kept alive by a Lens built outside the loop, belonged to that stream.)
+    Child processes: the graph path warms up 3 steps before capturing, the eager loop 1, hence 10 vs 12 steps."""
+    g = _adam_child("--graph", "--steps", "10")
+    e = _adam_child("--capturable", "--steps", "12")
+    assert g["hip_graph"] and not e["hip_graph"]
+    assert g["loss_initial"] == e["loss_initial"]
+    assert abs(g["loss_final"] - e["loss_final"]) <= 1e-6 * abs(e["loss_final"]), (g["loss_final"], e["loss_final"])
+    assert g["loss_final"] != g["loss_initial"]          # the replays really stepped the parameters
+
+
+def test_whole_adam_step_with_ray_aiming_replays_from_a_hip_graph():
+    g = _adam_child("--graph", "--steps", "6", "--aim", "1")
+    e = _adam_child("--capturable", "--steps", "8", "--aim", "1")
+    assert abs(g["loss_final"] - e["loss_final"]) <= 1e-6 * abs(e["loss_final"]), (g["loss_final"], e["loss_final"])

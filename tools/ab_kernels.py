@@ -50,9 +50,22 @@ def main():
     ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     libs = {}
+    import shutil
+    import tempfile
+    tmpdir = tempfile.mkdtemp(prefix="tl_ab_")
+    lib_env = {}
     for spec in a.libs:
-        name, path = spec.split("=")
-        dll = C.CDLL(os.path.join(ROOT, path))
+        # name=path[@VAR=value,VAR=value]: the launch-plan variables (TL_FWD_BLOCKS, TL_BWD_BLOCKS, ...) are read
+        # once per loaded library, so a variant with its own environment gets its own copy of the .so
+        name, path = spec.split("=", 1)
+        path, _, envs = path.partition("@")
+        src = os.path.join(ROOT, path)
+        if envs:
+            dst = os.path.join(tmpdir, f"lib_{name}.so")
+            shutil.copy(src, dst)
+            src = dst
+            lib_env[name] = dict(kv.split("=") for kv in envs.split(","))
+        dll = C.CDLL(src)
         dll.tl_version.restype = C.c_int
         ver = dll.tl_version()
         for fn, (res, argt) in _lib._SIGNATURES.items():
@@ -91,6 +104,9 @@ def main():
     ref = {}
     for rnd in range(a.rounds + 1):
         for name, dll in libs.items():
+            if rnd == 0:
+                for k_, v_ in lib_env.get(name, {}).items():
+                    os.environ[k_] = v_
             for key, fn in (("fwd", fwd), ("bwd", bwd), ("bwd_inv", bwd_inv)):
                 if key == "bwd_inv" and (dll._ver < 8 or a.workload == "cfg3a"):
                     continue
@@ -103,6 +119,8 @@ def main():
                     res[name][key].append(e0.elapsed_time(e1))
             if rnd == 0:
                 ref[name] = (mom.clone(), gpar.clone())
+                for k_ in lib_env.get(name, {}):
+                    os.environ.pop(k_, None)
     base = next(iter(libs))
     rays = F * W * P
     print(f"workload {a.workload} mode {a.mode}: F={F} W={W} P={P} S={S} ({rays} rays), {a.rounds} rounds")

@@ -32,9 +32,7 @@ tot = sum(sum(v) for v in d.values())
 for n, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:8]:
     print(f"{n:50s} calls {len(v):4d} avg {sum(v) / len(v) / 1e3:10.1f} us  {100 * sum(v) / tot:5.1f}%  vgpr/agpr/sgpr/lds/grid/wg {meta[n]}")
 
-for sub, names in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]),
-                   ("pmc_sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
-                               "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"])):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_grbm"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows(sub, "*counter_collection.csv"):
         n = r["Kernel_Name"].split("(")[0][-48:]

@@ -38,13 +38,16 @@ struct Plan { int nbx, R; };
 
 Plan make_plan(int P, int FW, int target, int rmax)
 {
+    // nbx blocks per (f, w), about `target` in total; each block takes an equal share (to within one) of the
+    // kBlock-point chunks of the pupil (TL_BLOCK_CHUNKS in tl_kernels.inc); R = the largest share
     const int64_t chunks = ((int64_t)P + kBlock - 1) / kBlock;
-    int64_t R = (chunks * FW + target - 1) / target;
-    if (R < 1) R = 1;
-    if (R > rmax) R = rmax;
+    int64_t nbx = (target + FW - 1) / FW;
+    if (nbx > chunks) nbx = chunks;
+    if (nbx * rmax < chunks) nbx = (chunks + rmax - 1) / rmax;
+    if (nbx < 1) nbx = 1;
     Plan pl;
-    pl.R = (int)R;
-    pl.nbx = (int)((chunks + R - 1) / R);
+    pl.nbx = (int)nbx;
+    pl.R = (int)((chunks + nbx - 1) / nbx);
     return pl;
 }
 
@@ -422,6 +425,15 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     static std::atomic<uint32_t> calls{0};
     uint32_t token = (calls.fetch_add(1u) + 1u) * 0x9E3779B1u;         // unique per call, nothing like stale data
     if (token == 0u) token = 1u;
+    {
+        // Recorded into a HIP graph, this call is replayed with the SAME token every time: a word poisoned by
+        // one replay would send every later replay to the checkpoint kernel (exact, but slower, silently).  So
+        // under capture -- and only there, a memset node costs ~6 us -- the word is cleared first.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+            if ((e = hipMemsetAsync(poison, 0, sizeof(unsigned), st)) != hipSuccess) return hip_fail(e, "hipMemsetAsync(poison)");
+        }
+    }
     int herr = (p->mode == TL_MODE_FAST)
                    ? tl_fast::api_bwd_inv(*p, gx, gy, gcx, gcy, g_moments, x_fwd, y_fwd, cx_fwd, cy_fwd, ok_fwd,
                                           moments_fwd, g_x_in, g_y_in, part, part_ck, poison, token, pl.nbx, pl.R, pk.nbx, pk.R, st)

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "../../include/tl_trace.h"
 
 // compile-time surface-row buckets of the backward kernel

@@ -20,6 +20,40 @@ import torch
 import torch.distributed as dist
 
 
+def init_group(device, backend: str = "nccl", force: bool = False):
+    """One process per GPU: join the job's process group and return it (None for a single process).
+
+    RANK / WORLD_SIZE / MASTER_* come from the launcher (torch.distributed.run).  `backend` "nccl" is RCCL
+    on ROCm.  `force=True` builds the group even for WORLD_SIZE=1 (a 1-rank RCCL communicator on this GPU):
+    every collective of the sharded path then really executes, which is how the path is exercised on a
+    one-GPU box."""
+    import os
+    import socket
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and not force:
+        return None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
+    return dist.group.WORLD
+
+
+def ranks_seen(group, device) -> int:
+    """Sum of a one over the ranks of `group`, computed by the collective itself on `device`."""
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
+    return int(round(one.item()))
+
+
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [start, stop) slice of n pupil points owned by `rank` (sizes differ by <= 1)."""
     base, extra = divmod(n, world)

@@ -28,8 +28,10 @@ _MODES = ('skew_random', 'tee', 'circular', 'skew_uniform_half_equidistant', 'sk
 # ---------------------------------------------------------------------------- pupil samplers
 def tee(tensor=None, device="cuda"):
     """Bottom and top meridional rays and the +x sagittal ray, shape [1,1,3,1]."""
-    y = torch.tensor([-1., 1., 0.], device=device).reshape(1, 1, 3, 1)
-    x = torch.tensor([0., 0., 1.], device=device).reshape(1, 1, 3, 1)
+    # cached constants: no host-to-device copy per call, so ray aiming can sit inside a captured HIP graph
+    from .lens_modeling import const_tensor
+    y = const_tensor([-1., 1., 0.], torch.float32, device, (1, 1, 3, 1))
+    x = const_tensor([0., 0., 1.], torch.float32, device, (1, 1, 3, 1))
     return x, y
 
 
