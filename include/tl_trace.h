@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 10
+#define TL_ABI_VERSION 11
 #define TL_MAX_SURFACES 32       /* rows per lens the backward kernels are built for */
 #define TL_NMOM 10               /* per-field sums, see tl_trace_fwd */
 #define TL_MAX_POLY 4            /* even aspheric terms a4,a6,a8,a10 */
@@ -52,7 +52,8 @@ typedef struct tl_problem {
     int32_t device;              /* HIP device ordinal the pointers live on */
     int32_t mode;                /* TL_MODE_* */
     int32_t allow_backward;      /* allow_backward_rays (ray_tracing_lite.py:629) */
-    int32_t aggregate;           /* aggregate=True of trace_skew (:641-657): evaluate the penalty-term quantities */
+    int32_t aggregate;           /* aggregate=True of trace_skew (:641-657): evaluate the penalty-term quantities
+                                    (aspheric rows included: theta from the cosine at the aspheric normal) */
     /* entrance-pupil ray coordinates; element strides (floats) over (f, p, w), 0 = broadcast.
        Reference shapes [1|B, 1|F, P, 1|W] (ray_tracing_lite.py:112-113). */
     const float *x_in, *y_in;
@@ -90,8 +91,8 @@ size_t tl_workspace_bytes(const tl_problem *p);
  *   x,y,cx,cy : [F,W,P] float  (any may be NULL = not wanted)
  *   ok,back   : [F,W,P] uint8  (nullable)
  *   opd       : [F,W,P] float  optical path length sum_k n_k d_k + n_S d_image from the pupil plane
- *               to the image plane, 0 for failed rays; needs p->n_index (nullable; extension,
- *               forward only: no gradient flows through it)
+ *               to the image plane, 0 for failed rays; needs p->n_index (nullable; extension; its gradient:
+ *               `g_opd` of tl_trace_bwd)
  *   moments   : [F,TL_NMOM] double (nullable), per field over (w,p):
  *               0 sum y | 1 sum ok*y | 2 sum ok*y^2 | 3 sum ok | 4 sum x | 5 sum ok*x |
  *               6 sum ok*x^2 | 7 sum back | 8 sum q (p->aggregate only) |
@@ -114,6 +115,9 @@ int tl_trace_fwd(const tl_problem *p,
  * (SURVEY 3.4).  Recomputes the forward per ray in registers, then sweeps the surfaces in
  * reverse.
  *   gx,gy,gcx,gcy : [F,W,P] upstream gradients of the per-ray outputs (each nullable)
+ *   g_opd         : [F,W,P] upstream gradient of the optical path length output (nullable; needs p->n_index and
+ *                   g_n_index).  OPD = sum_k n_k d_k + n_S d_image: it enters the adjoint of every marching distance
+ *                   and so reaches c, t, mu, z, cx, cy, kappa, poly, x_in, y_in; g_n_index [W,S+1] = d/d n_index
  *   g_moments     : [F,TL_NMOM] double upstream gradient of `moments` (nullable); the per-ray
  *                   seed  gM0 + ok*(gM1 + 2*y*gM2)  (and the x analogue) is formed in-kernel;
  *                   entry 8 seeds the penalty term when p->aggregate
@@ -125,9 +129,9 @@ int tl_trace_fwd(const tl_problem *p,
  */
 int tl_trace_bwd(const tl_problem *p,
                  const float *gx, const float *gy, const float *gcx, const float *gcy,
-                 const double *g_moments,
+                 const double *g_moments, const float *g_opd,
                  float *g_c, float *g_t, float *g_mu, float *g_z, float *g_cx, float *g_cy,
-                 float *g_kappa, float *g_poly,
+                 float *g_kappa, float *g_poly, float *g_n_index,
                  float *g_x_in, float *g_y_in,
                  void *workspace, size_t workspace_bytes, void *stream);
 
@@ -144,7 +148,7 @@ int tl_trace_bwd(const tl_problem *p,
  *   - `moments_fwd` (the forward's moments, nullable) counts an ill-conditioned live ray, or
  *   - the walk-back met a non-finite adjoint (it then flags a word at the end of the workspace).
  * Pass `moments_fwd` whenever it is available: without it an ill-conditioned fan is walked back anyway.
- * allow_backward = 1 and aggregate = 0 only (TL_EINVAL otherwise: use tl_trace_bwd).  Aspheric rows are walked
+ * allow_backward = 1 and aggregate = 0 only, no OPD gradient (TL_EINVAL otherwise: use tl_trace_bwd).  Aspheric rows are walked
  * back too (Newton on the reversed ray; g_kappa, g_poly as in tl_trace_bwd, required iff p->surf_kind).
  * Workspace: tl_workspace_bytes(p); its contents need not be initialised.
  */

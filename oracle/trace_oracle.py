@@ -164,6 +164,30 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate: bool = False,
         _IEEE = prev
 
 
+def _push_stacks(stacks, r: RayBundle, cos2_i, cos2_t, n_wave: int) -> None:
+    """Penalty-term raw material of one surface row (ref :641-657): z_RELU, theta/(pi/2), theta'/(pi/2)."""
+    full = (*r.x.shape[:3], n_wave)
+    z_relu = torch.where(r.z <= 0, torch.zeros_like(r.z), r.z)
+    lo, hi = -1.0 + ACOS_EPS, 1.0 - ACOS_EPS
+    # The reference takes sqrt(cos2) of EVERY ray and overwrites theta of the dead ones with 1
+    # afterwards (in place, which only works when shapes already agree: SURVEY Appendix B5).
+    # For a missed ray cos2 < 0, sqrt is NaN, and although the forward value is overwritten the
+    # backward multiplies a zero gradient by NaN: the reference's penalty gradient is NaN as soon
+    # as one ray misses.  Same forward values here, but the sqrt argument of dead rays is
+    # replaced by 1 first, so masked rays contribute exactly zero gradient.
+    ok_b = torch.broadcast_to(r.ok, full)
+    one = torch.ones((), dtype=r.x.dtype, device=r.x.device)
+    safe_i = torch.where(ok_b, torch.broadcast_to(cos2_i, full), one)
+    safe_t = torch.where(ok_b, torch.broadcast_to(cos2_t, full), one)
+    th_i = torch.acos(torch.clamp(torch.sqrt(safe_i), min=lo, max=hi)) / (1 / 2 * math.pi)
+    th_t = torch.acos(torch.clamp(torch.sqrt(safe_t), min=lo, max=hi)) / (1 / 2 * math.pi)
+    th_i = torch.where(ok_b, th_i, one)
+    th_t = torch.where(ok_b, th_t, one)
+    stacks['z_RELU'].append(torch.broadcast_to(z_relu, full))
+    stacks['theta_norm'].append(th_i)
+    stacks['theta_prime_norm'].append(th_t)
+
+
 def _trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays):
     n_surf = t.shape[-1]
     cs, ts, mus, masks = (torch.unbind(a, dim=-1) for a in (c, t, mu, mask))
@@ -185,27 +209,8 @@ def _trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays)
         retire_dead(r)
         r.z = r.z - ts[k]
 
-        if aggregate:   # ref :641-657 (penalty-term raw material)
-            full = (*r.x.shape[:3], n_wave)
-            z_relu = torch.where(r.z <= 0, torch.zeros_like(r.z), r.z)
-            lo, hi = -1.0 + ACOS_EPS, 1.0 - ACOS_EPS
-            # The reference takes sqrt(cos2) of EVERY ray and overwrites theta of the dead ones with 1
-            # afterwards (in place, which only works when shapes already agree: SURVEY Appendix B5).
-            # For a missed ray cos2 < 0, sqrt is NaN, and although the forward value is overwritten the
-            # backward multiplies a zero gradient by NaN: the reference's penalty gradient is NaN as soon
-            # as one ray misses.  Same forward values here, but the sqrt argument of dead rays is
-            # replaced by 1 first, so masked rays contribute exactly zero gradient.
-            ok_b = torch.broadcast_to(r.ok, full)
-            one = torch.ones((), dtype=r.x.dtype, device=r.x.device)
-            safe_i = torch.where(ok_b, torch.broadcast_to(cos2_i, full), one)
-            safe_t = torch.where(ok_b, torch.broadcast_to(cos2_t, full), one)
-            th_i = torch.acos(torch.clamp(torch.sqrt(safe_i), min=lo, max=hi)) / (1 / 2 * math.pi)
-            th_t = torch.acos(torch.clamp(torch.sqrt(safe_t), min=lo, max=hi)) / (1 / 2 * math.pi)
-            th_i = torch.where(ok_b, th_i, one)
-            th_t = torch.where(ok_b, th_t, one)
-            stacks['z_RELU'].append(torch.broadcast_to(z_relu, full))
-            stacks['theta_norm'].append(th_i)
-            stacks['theta_prime_norm'].append(th_t)
+        if aggregate:
+            _push_stacks(stacks, r, cos2_i, cos2_t, n_wave)
 
     # transfer to the image plane (ref :659-663)
     dz = -r.z
@@ -289,13 +294,16 @@ def refract_general(mu, r: RayBundle, dsag, rho):
 
 
 def trace_skew_general(x, y, z, cx, cy, c, t, mu, mask, kappa=None, poly=None, kind=None,
-                       allow_backward_rays: bool = True, n_index=None, ieee_sqrt: bool = False):
+                       allow_backward_rays: bool = True, n_index=None, ieee_sqrt: bool = False,
+                       aggregate: bool = False):
     """trace_skew with optional aspheric rows and optical path length.
 
     kappa [S], poly [S,4] (a4, a6, a8, a10), kind: sequence of S ints (0 sphere closed form,
     1 Newton asphere); n_index [1,1,1,W,S+1] refractive indices (index 0 = object space) for OPD.
     Returns (x, y, cx, cy, ray_ok, ray_backward, opd) with opd = sum_k n_k d_k + n_S dist_image
     (None when n_index is None).  Dead rays: opd = 0.
+    aggregate=True appends the penalty-term `stacks` (as trace_skew does); at an aspheric row theta comes
+    from the cosine between the ray and the aspheric normal.
     """
     global _IEEE
     prev, _IEEE = _IEEE, bool(ieee_sqrt)
@@ -307,9 +315,10 @@ def trace_skew_general(x, y, z, cx, cy, c, t, mu, mask, kappa=None, poly=None, k
         r = RayBundle(x, y, z, cx, cy, _sqrt(1 - cx ** 2 - cy ** 2),
                       torch.ones_like(y, dtype=torch.bool), torch.zeros_like(y, dtype=torch.bool))
         opd = None if ns is None else torch.zeros_like(y)
+        stacks: Dict[str, List[torch.Tensor]] = {'z_RELU': [], 'theta_norm': [], 'theta_prime_norm': []}
         for k in range(n_surf):
             if kind[k] == 0:
-                miss, d, cos_i, _ = sphere_hit(cs[k], r)
+                miss, d, cos_i, cos2_i = sphere_hit(cs[k], r)
                 dz = advance(r, d)
             else:
                 miss, d, X, Y, dsag, rho = asphere_hit(cs[k], kappa[k], poly[k], r)
@@ -318,9 +327,9 @@ def trace_skew_general(x, y, z, cx, cy, c, t, mu, mask, kappa=None, poly=None, k
             r.ok = r.ok & ~miss
             retire_dead(r)
             if kind[k] == 0:
-                fail, _ = refract_sphere(cs[k], mus[k], r, cos_i)
+                fail, cos2_t = refract_sphere(cs[k], mus[k], r, cos_i)
             else:
-                fail, _, _ = refract_general(mus[k], r, dsag, rho)
+                fail, cos2_i, cos2_t = refract_general(mus[k], r, dsag, rho)
             if k > 0:
                 _flag_backward(r, dz, r.ok & masks[k - 1], allow_backward_rays)
             r.ok = r.ok & ~fail
@@ -328,6 +337,8 @@ def trace_skew_general(x, y, z, cx, cy, c, t, mu, mask, kappa=None, poly=None, k
             r.z = r.z - ts[k]
             if opd is not None:
                 opd = torch.where(r.ok, opd + ns[k] * d, torch.zeros_like(opd + ns[k] * d))
+            if aggregate:
+                _push_stacks(stacks, r, cos2_i, cos2_t, mus[0].shape[-1])
         dz = -r.z
         dist = dz / r.cz
         r.x = r.x + dist * r.cx
@@ -335,6 +346,8 @@ def trace_skew_general(x, y, z, cx, cy, c, t, mu, mask, kappa=None, poly=None, k
         if opd is not None:
             opd = torch.where(r.ok, opd + ns[-1] * dist, torch.zeros_like(opd + ns[-1] * dist))
         _flag_backward(r, dz, r.ok & masks[-1], allow_backward_rays)
+        if aggregate:
+            return r.x, r.y, r.cx, r.cy, r.ok, r.back, opd, stacks
         return r.x, r.y, r.cx, r.cy, r.ok, r.back, opd
     finally:
         _IEEE = prev

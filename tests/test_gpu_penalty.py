@@ -104,8 +104,18 @@ def test_full_chain_harness_equivalent_matches_reference(ta):
         assert err <= 3e-4, f"d loss_unsup / d{k}: {err:.2e}"     # fp32 autograd through acos near 1 is itself ~1e-4 noisy
 
 
-def test_aggregate_with_aspheres_is_refused(ta):
-    g = load_golden("G2_cooke_16x16")
-    ins = [torch.from_numpy(g[n]).to(DEV) for n in IN]
-    with pytest.raises(NotImplementedError):
-        ta.trace_skew(*ins, torch.from_numpy(g["in_mask"]).to(DEV), True, True, kappa=torch.full((7,), -0.5, device=DEV))
+def test_full_loss_of_the_real_caller_on_the_two_asphere_double_gauss(ta):
+    """BASELINE configs[2] as written through the real caller's loss (rms + penalty_rate * sumQ,
+    optics_simulator_lite.py:430-450): round 1 refused aggregate=True on aspheric lenses."""
+    from torchoptics_amd import prescriptions as P, ray_tracing as rt
+    lens, specs, leaves = P.double_gauss(DEV, aspheres=True)
+    tr = ta.RayTracer(mode="circular", n_rays=(16, 16), rel_fields=(0., 0.707, 1.), wavelengths=[459., 520., 640.],
+                      n_ray_aiming_iter=1, default_device=DEV)
+    out = tr.trace_rays(specs, lens, aggregate=True)
+    ld = rt.unsupervised_loss(out, 11, 0.2)
+    assert all(torch.isfinite(ld[k]).item() for k in ("loss_unsup", "rms", "penalty"))
+    assert abs(ld["loss_unsup"].item() - (ld["rms"].item() + 0.2 * ld["penalty"].item())) <= 1e-5 * abs(ld["loss_unsup"].item())
+    ld["loss_unsup"].backward()
+    for k in ("c", "t", "nd", "kappa", "poly"):
+        assert leaves[k].grad is not None and torch.isfinite(leaves[k].grad).all(), k
+    assert leaves["kappa"].grad[1].abs().item() > 0 and leaves["kappa"].grad[10].abs().item() > 0

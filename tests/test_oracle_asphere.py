@@ -89,3 +89,53 @@ def test_optical_path_length_is_consistent():
     want = -ins[2].reshape(()) * n[0, 0, 0, :, 0] + (n[0, 0, 0, :, 1:] * ins[6].reshape(1, S)).sum(dim=1)
     assert torch.allclose(axis, want, rtol=0, atol=1e-9)
     assert (opd[o[4]] > 0).all() and (opd[~o[4]] == 0).all()
+
+
+def _n_index(mu, dtype):
+    """[1,1,1,W,S+1] refractive indices with n_0 = 1 and n_k / n_{k+1} = mu_k."""
+    S = mu.shape[-1]
+    n = [torch.ones(1, 1, 1, mu.shape[3], dtype=dtype)]
+    for k in range(S):
+        n.append(n[-1] / mu[..., k])
+    return torch.stack(n, dim=-1)
+
+
+def test_general_aggregate_on_spherical_rows_is_the_reference_penalty():
+    ins, mask = _case()
+    a = orc.trace_skew(*ins, mask, aggregate=True)
+    b = orc.trace_skew_general(*ins, mask, aggregate=True)
+    for key in ("z_RELU", "theta_norm", "theta_prime_norm"):
+        assert all(torch.equal(p, q) for p, q in zip(a[6][key], b[7][key])), key
+
+
+def test_penalty_and_opd_gradients_on_aspheric_rows_match_finite_differences():
+    """The two round-2 extensions of the definition: the penalty term with aspheric rows (theta from the cosine at
+    the aspheric normal) and the gradient THROUGH the optical path length, incl. d/d n_index; fp64, central
+    differences."""
+    ins, mask = _case(torch.float64)
+    S = ins[5].shape[-1]
+    kap, pol, kind = asphere_params(S, torch.float64)
+    n = _n_index(ins[7], torch.float64)
+    kap.requires_grad_(True)
+    c = ins[5].clone().requires_grad_(True)
+    t = ins[6].clone().requires_grad_(True)
+    n.requires_grad_(True)
+    torch.manual_seed(3)
+    w_opd = torch.rand(1, ins[4].shape[1], ins[0].shape[2], n.shape[3], dtype=torch.float64)
+
+    def loss():
+        o = orc.trace_skew_general(ins[0], ins[1], ins[2], ins[3], ins[4], c, t, ins[7], mask, kap, pol, kind,
+                                   n_index=n, aggregate=True)
+        return (o[6] * w_opd).sum() * 1e-3 + orc.penalty_from_stacks(o[7], S) * 1e-2
+    loss().backward()
+    for tens, idx, h in ((kap, (0,), 1e-6), (kap, (5,), 1e-6), (c, (0, 0, 0, 0, 0), 1e-7), (c, (0, 0, 0, 0, 3), 1e-7),
+                         (t, (0, 0, 0, 0, 2), 1e-6), (n, (0, 0, 0, 1, 3), 1e-7), (n, (0, 0, 0, 0, S), 1e-7)):
+        with torch.no_grad():
+            base = tens[idx].item()
+            tens[idx] = base + h
+            lp = loss().item()
+            tens[idx] = base - h
+            lm_ = loss().item()
+            tens[idx] = base
+        fd = (lp - lm_) / (2 * h)
+        assert abs(tens.grad[idx].item() - fd) <= 5e-5 * abs(fd) + 1e-9, (idx, tens.grad[idx].item(), fd)

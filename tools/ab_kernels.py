@@ -77,6 +77,8 @@ def main():
                 argt = argt[:8] + argt[9:]
             if fn == "tl_trace_bwd_from_outputs" and ver < 9:   # older ABI: no g_kappa, g_poly
                 argt = argt[:-5] + argt[-3:]
+            if fn == "tl_trace_bwd" and ver < 11:               # older ABI: no g_opd, g_n_index
+                argt = argt[:-5] + argt[-3:]
             f.argtypes = argt
         dll._ver = ver
         libs[name] = dll
@@ -89,8 +91,9 @@ def main():
         assert rc == 0, dll.tl_last_error()
 
     def bwd(dll):
-        rc = dll.tl_trace_bwd(C.byref(prob), None, None, None, None, P_(gmom), P_(g_c), P_(g_t), P_(g_mu), P_(g_z),
-                              P_(g_cx), P_(g_cy), None, None, None, None, P_(ws), ws.numel(), st)
+        opd_args = ((None,), (None,)) if dll._ver >= 11 else ((), ())       # ABI 11: g_opd, g_n_index
+        rc = dll.tl_trace_bwd(C.byref(prob), None, None, None, None, P_(gmom), *opd_args[0], P_(g_c), P_(g_t), P_(g_mu),
+                              P_(g_z), P_(g_cx), P_(g_cy), None, None, *opd_args[1], None, None, P_(ws), ws.numel(), st)
         assert rc == 0, dll.tl_last_error()
 
     def bwd_inv(dll):

@@ -9,9 +9,10 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtltrace.so")
+# TORCHOPTICS_AMD_LIB: another build of the same library (an A/B variant written by build.build_library(tag=...))
+LIB_PATH = os.environ.get("TORCHOPTICS_AMD_LIB") or os.path.join(_HERE, "libtltrace.so")
 
-TL_ABI_VERSION = 10
+TL_ABI_VERSION = 11
 TL_NMOM = 10
 TL_MAX_SURFACES = 32
 TL_MAX_POLY = 4
@@ -42,7 +43,7 @@ _SIGNATURES = {
     "tl_problem_size": (C.c_size_t, []),
     "tl_workspace_bytes": (C.c_size_t, [C.POINTER(tl_problem)]),
     "tl_trace_fwd": (C.c_int, [C.POINTER(tl_problem)] + [_VP] * 9 + [_VP, C.c_size_t, _VP]),
-    "tl_trace_bwd": (C.c_int, [C.POINTER(tl_problem)] + [_VP] * 15 + [_VP, C.c_size_t, _VP]),
+    "tl_trace_bwd": (C.c_int, [C.POINTER(tl_problem)] + [_VP] * 17 + [_VP, C.c_size_t, _VP]),
     "tl_trace_bwd_from_outputs": (C.c_int, [C.POINTER(tl_problem)] + [_VP] * 21 + [_VP, C.c_size_t, _VP]),
     "tl_spot_moments": (C.c_int, [C.c_int32] * 4 + [_VP] * 3 + [C.c_int64] * 3 + [_VP, _VP, C.c_size_t, _VP]),
     "tl_spot_rms": (C.c_int, [C.c_int32, C.c_int32, C.c_double, _VP, _VP, _VP, _VP]),

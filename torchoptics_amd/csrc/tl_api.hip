@@ -77,7 +77,6 @@ int check_problem(const tl_problem *p)
     if ((p->cx_stride | 1) != 1 || (p->cy_stride | 1) != 1) return fail(TL_EINVAL, "cx/cy stride must be 0 or 1");
     if ((p->surf_kind != nullptr) != (p->kappa != nullptr) || (p->surf_kind != nullptr) != (p->poly != nullptr))
         return fail(TL_EINVAL, "surf_kind, kappa and poly must be given together (or all NULL)");
-    if (p->aggregate && p->surf_kind) return fail(TL_EINVAL, "aggregate (penalty term) is built for all-spherical lenses only");
     if (p->aggregate && p->S > 31) return fail(TL_EINVAL, "aggregate needs S <= 31");
     return TL_OK;
 }
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
                                                             const double *__restrict__ alt_part, int alt_NS,
                                                             const double *__restrict__ fmom,
                                                             const unsigned *__restrict__ poison,
-                                                            unsigned token, int alt_nbx)
+                                                            unsigned token, int alt_nbx, float *__restrict__ g_n)
 {
     __shared__ double sm[kBlock];
     // two candidate partial arrays (walk-back kernel / checkpoint fallback): the forward's conditioning count
@@ -140,20 +139,28 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
         if (fmom)
             for (int f = 0; f < F; ++f) n += fmom[(size_t)f * TL_NMOM + 9];
         if (n > 0.0 || (poison && *poison == token)) {
-            part = alt_part; NS = alt_NS; ncol = (g_kappa ? 8 : 3) * alt_NS + 3; nbx = alt_nbx;
+            part = alt_part; NS = alt_NS; ncol = tl_bwd_row(alt_NS, g_kappa != nullptr); nbx = alt_nbx;
         }
     }
+    // one block per output scalar: g_c[S] | g_t[S] | g_mu[W,S] | g_z | g_cx[F] | g_cy[F] [| g_kappa[S] | g_poly[S,4]] [| g_n[W,S+1]]
     int b = blockIdx.x;
     float *out;
     int col, f0 = 0, nf = F, w0 = 0, nw = W;
+    const int n_asph = g_kappa ? 5 * S : 0;
     if (b < S) { col = b; out = g_c + b; }
     else if ((b -= S) < S) { col = NS + b; out = g_t + b; }
     else if ((b -= S) < W * S) { const int w = b / S, k = b % S; col = 2 * NS + k; w0 = w; nw = 1; out = g_mu + b; }
     else if ((b -= W * S) < 1) { col = 3 * NS; out = g_z; }
     else if ((b -= 1) < F) { col = 3 * NS + 1; f0 = b; nf = 1; out = g_cx + b; }
     else if ((b -= F) < F) { col = 3 * NS + 2; f0 = b; nf = 1; out = g_cy + b; }
-    else if ((b -= F) < S) { col = 3 * NS + 3 + b; out = g_kappa + b; }                 // aspheric rows only
-    else { b -= S; col = 4 * NS + 3 + b; out = g_poly + b; }                             // b = 4k + j
+    else if ((b -= F) < n_asph) {                                                        // aspheric rows only
+        if (b < S) { col = 3 * NS + 3 + b; out = g_kappa + b; }
+        else { col = 4 * NS + 3 + (b - S); out = g_poly + (b - S); }                     // b - S = 4k + j
+    } else {                                                                             // g_n[w][k], k <= S (OPD gradient only)
+        b -= n_asph;
+        const int w = b / (S + 1), k = b % (S + 1);
+        col = (g_kappa ? 8 : 3) * NS + 3 + k; w0 = w; nw = 1; out = g_n + b;
+    }
     const double s = sum_rows(part, ncol, col, W, nbx, f0, nf, w0, nw, sm);
     if (threadIdx.x == 0) *out = (float)s;        // summed in fp64, rounded once
 }
@@ -319,6 +326,7 @@ int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, 
     if (rc) return rc;
     if (stacks && !p->aggregate) return fail(TL_EINVAL, "the stacks output needs tl_problem.aggregate");
     if (opd && !p->n_index) return fail(TL_EINVAL, "the opd output needs tl_problem.n_index");
+    if (opd && p->aggregate) return fail(TL_EINVAL, "the opd output and aggregate (penalty term) cannot be combined in one call");
     if (p->P == 0) {
         if (moments) {
             hipError_t e = hipMemsetAsync(moments, 0, (size_t)p->F * TL_NMOM * sizeof(double), (hipStream_t)stream);
@@ -350,12 +358,14 @@ int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, 
 }
 
 int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const float *gcx, const float *gcy,
-                 const double *g_moments, float *g_c, float *g_t, float *g_mu, float *g_z, float *g_cx,
-                 float *g_cy, float *g_kappa, float *g_poly, float *g_x_in, float *g_y_in, void *workspace,
+                 const double *g_moments, const float *g_opd, float *g_c, float *g_t, float *g_mu, float *g_z, float *g_cx,
+                 float *g_cy, float *g_kappa, float *g_poly, float *g_n_index, float *g_x_in, float *g_y_in, void *workspace,
                  size_t workspace_bytes, void *stream)
 {
     int rc = check_problem(p);
     if (rc) return rc;
+    if ((g_opd != nullptr) != (g_n_index != nullptr)) return fail(TL_EINVAL, "g_opd and g_n_index must be given together");
+    if (g_opd && !p->n_index) return fail(TL_EINVAL, "the gradient of the optical path length needs tl_problem.n_index");
     if (!g_c || !g_t || !g_mu || !g_z || !g_cx || !g_cy) return fail(TL_EINVAL, "a parameter-gradient output is NULL");
     if ((g_kappa || g_poly) && !p->surf_kind) return fail(TL_EINVAL, "g_kappa / g_poly need aspheric rows (surf_kind)");
     if (p->surf_kind && (!g_kappa || !g_poly)) return fail(TL_EINVAL, "aspheric rows need g_kappa and g_poly outputs");
@@ -367,7 +377,8 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
         if ((e = hipMemsetAsync(g_c, 0, S * 4, st)) || (e = hipMemsetAsync(g_t, 0, S * 4, st)) ||
             (e = hipMemsetAsync(g_mu, 0, S * p->W * 4, st)) || (e = hipMemsetAsync(g_z, 0, 4, st)) ||
             (e = hipMemsetAsync(g_cx, 0, (size_t)p->F * 4, st)) || (e = hipMemsetAsync(g_cy, 0, (size_t)p->F * 4, st)) ||
-            (g_kappa && (e = hipMemsetAsync(g_kappa, 0, S * 4, st))) || (g_poly && (e = hipMemsetAsync(g_poly, 0, S * 16, st))))
+            (g_kappa && (e = hipMemsetAsync(g_kappa, 0, S * 4, st))) || (g_poly && (e = hipMemsetAsync(g_poly, 0, S * 16, st))) ||
+            (g_n_index && (e = hipMemsetAsync(g_n_index, 0, (S + 1) * p->W * 4, st))))
             return hip_fail(e, "hipMemsetAsync(grads)");
         return TL_OK;
     }
@@ -379,13 +390,13 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
     if (!workspace || workspace_bytes < need) return fail(TL_EWORKSPACE, "workspace too small for tl_trace_bwd");
     double *part = (double *)workspace;
     int herr = (p->mode == TL_MODE_FAST)
-                   ? tl_fast::api_bwd(*p, gx, gy, gcx, gcy, g_moments, g_x_in, g_y_in, part, pl.nbx, pl.R, st)
-                   : tl_strict::api_bwd(*p, gx, gy, gcx, gcy, g_moments, g_x_in, g_y_in, part, pl.nbx, pl.R, st);
+                   ? tl_fast::api_bwd(*p, gx, gy, gcx, gcy, g_moments, g_x_in, g_y_in, part, pl.nbx, pl.R, st, g_opd)
+                   : tl_strict::api_bwd(*p, gx, gy, gcx, gcy, g_moments, g_x_in, g_y_in, part, pl.nbx, pl.R, st, g_opd);
     if (herr) return hip_fail(herr, "trace_bwd_kernel launch");
-    const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0);
+    const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0) + (g_opd ? p->W * (p->S + 1) : 0);
     hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout), dim3(kBlock), 0, st, part, ns, p->F, p->W, p->S, pl.nbx, g_c,
                        g_t, g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly, (const double *)nullptr, 0,
-                       (const double *)nullptr, (const unsigned *)nullptr, 0u, 0);
+                       (const double *)nullptr, (const unsigned *)nullptr, 0u, 0, g_n_index);
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");
     return TL_OK;
@@ -406,8 +417,8 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
         return fail(TL_EINVAL, "tl_trace_bwd_from_outputs: allow_backward_rays and no penalty term only");
     if ((g_kappa || g_poly) && !p->surf_kind) return fail(TL_EINVAL, "g_kappa / g_poly need aspheric rows (surf_kind)");
     if (p->surf_kind && (!g_kappa || !g_poly)) return fail(TL_EINVAL, "aspheric rows need g_kappa and g_poly outputs");
-    if (p->P == 0) return tl_trace_bwd(p, gx, gy, gcx, gcy, g_moments, g_c, g_t, g_mu, g_z, g_cx, g_cy, g_kappa, g_poly,
-                                       g_x_in, g_y_in, workspace, workspace_bytes, stream);
+    if (p->P == 0) return tl_trace_bwd(p, gx, gy, gcx, gcy, g_moments, nullptr, g_c, g_t, g_mu, g_z, g_cx, g_cy, g_kappa, g_poly,
+                                       nullptr, g_x_in, g_y_in, workspace, workspace_bytes, stream);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSetDevice(p->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
@@ -443,7 +454,7 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0);
     hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout), dim3(kBlock), 0, st, part, p->S, p->F, p->W, p->S, pl.nbx, g_c, g_t,
                        g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly, (const double *)part_ck, ns,
-                       moments_fwd, (const unsigned *)poison, token, pk.nbx);
+                       moments_fwd, (const unsigned *)poison, token, pk.nbx, (float *)nullptr);
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");
     return TL_OK;

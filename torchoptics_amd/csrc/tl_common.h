@@ -2,8 +2,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
-#include <type_traits>
 #include "../../include/tl_trace.h"
 
 // compile-time surface-row buckets of the backward kernel
@@ -15,7 +13,8 @@ static inline int tl_bwd_bucket(int S)
 }
 
 // doubles per block-partial row of the backward kernel (see trace_bwd_kernel)
-static inline int tl_bwd_row(int ns, bool asph) { return (asph ? 8 : 3) * ns + 3; }
+// g_c | g_t | g_mu [NS each] | g_z g_cx g_cy | [g_kappa[NS] | g_poly[NS][4]] | g_n[NS+1]
+__host__ __device__ static inline int tl_bwd_row(int ns, bool asph) { return (asph ? 8 : 3) * ns + 3 + ns + 1; }
 
 // per-mode launchers (defined in tl_strict.hip / tl_fast.hip); return hipError_t as int
 #define TL_DECLARE_MODE(NS)                                                                          \
@@ -25,7 +24,7 @@ static inline int tl_bwd_row(int ns, bool asph) { return (asph ? 8 : 3) * ns + 3
                 hipStream_t st);                                                                     \
     int api_bwd(const tl_problem &p, const float *gx, const float *gy, const float *gcx,              \
                 const float *gcy, const double *gmom, float *gxin, float *gyin, double *part,         \
-                int nbx, int R, hipStream_t st);                                                     \
+                int nbx, int R, hipStream_t st, const float *gopd);                                  \
     int api_bwd_inv(const tl_problem &p, const float *gx, const float *gy, const float *gcx,          \
                     const float *gcy, const double *gmom, const float *fx, const float *fy,           \
                     const float *fcx, const float *fcy, const uint8_t *fok, const double *fmom,       \

@@ -10,8 +10,9 @@ int api_fwd(const tl_problem &p, float *x, float *y, float *cx, float *cy, uint8
             float *opd, float *stacks, double *part, int nbx, int R, hipStream_t st)
 { return tl_strict_impl::launch_fwd(p, x, y, cx, cy, ok, back, opd, stacks, part, nbx, R, st); }
 int api_bwd(const tl_problem &p, const float *gx, const float *gy, const float *gcx, const float *gcy,
-            const double *gmom, float *gxin, float *gyin, double *part, int nbx, int R, hipStream_t st)
-{ return tl_strict_impl::launch_bwd(p, gx, gy, gcx, gcy, gmom, gxin, gyin, part, nbx, R, st); }
+            const double *gmom, float *gxin, float *gyin, double *part, int nbx, int R, hipStream_t st,
+            const float *gopd)
+{ return tl_strict_impl::launch_bwd(p, gx, gy, gcx, gcy, gmom, gxin, gyin, part, nbx, R, st, nullptr, nullptr, 0u, gopd); }
 int api_bwd_inv(const tl_problem &p, const float *gx, const float *gy, const float *gcx, const float *gcy,
                 const double *gmom, const float *fx, const float *fy, const float *fcx, const float *fcy,
                 const uint8_t *fok, const double *fmom, float *gxin, float *gyin, double *part_inv, double *part_ck,

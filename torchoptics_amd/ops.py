@@ -150,8 +150,6 @@ class TraceFunction(torch.autograd.Function):
         if S > _lib.TL_MAX_SURFACES:
             raise RuntimeError(f"lens has {S} rows; this build supports at most {_lib.TL_MAX_SURFACES}")
         lib = _lib.lib()
-        if aggregate and kind_u8 is not None:
-            raise NotImplementedError("aggregate=True (penalty term) is built for all-spherical lenses only")
         prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa, poly, kind_u8, n_index, aggregate)
         nbytes = lib.tl_workspace_bytes(C.byref(prob))
         ws = _workspace(nbytes, dev)
@@ -170,10 +168,12 @@ class TraceFunction(torch.autograd.Function):
         _lib.check(rc, "tl_trace_fwd")
         # per-ray input gradients (ray aiming: a handful of rays) keep the checkpoint algorithm: extreme rays
         # amplify the reconstruction rounding of the walk-back to ~1e-4 in d/dx_in, d/dy_in
-        use_inv = (_bwd_algo == "inverse" and want_rays and not aggregate and allow_back
+        # ... and so does the gradient through the optical path length (only the checkpoint kernel carries it)
+        use_inv = (_bwd_algo == "inverse" and want_rays and not aggregate and allow_back and not want_opd
                    and not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         fwd_out = (fp[0], fp[1], fp[2], fp[3], bp[0], moments) if use_inv else (None,) * 6
-        ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, *fwd_out)
+        ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, *fwd_out,
+                              n_index if want_opd else None)
         ctx.allow_back, ctx.mode, ctx.aggregate, ctx.use_inv = allow_back, mode, aggregate, use_inv
         ctx.set_materialize_grads(False)
         if want_rays:
@@ -184,29 +184,34 @@ class TraceFunction(torch.autograd.Function):
             flags = [torch.empty(0, dtype=torch.bool, device=dev) for _ in range(2)]
         opd_out = opd.permute(0, 1, 3, 2) if want_opd else torch.empty(0, device=dev)
         stk_out = stacks.permute(0, 1, 2, 3, 5, 4) if stacks is not None else torch.empty(0, device=dev)
-        ctx.mark_non_differentiable(*flags, opd_out, stk_out)
+        ctx.mark_non_differentiable(*flags, stk_out)
+        if not want_opd:
+            ctx.mark_non_differentiable(opd_out)
         return (*outs, *flags, moments, opd_out, stk_out)
 
     @staticmethod
-    def backward(ctx, gx, gy, gcx, gcy, _gok, _gback, gmom, _gopd, _gstk):
-        x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, fx, fy, fcx, fcy, fok, fmom = ctx.saved_tensors
+    def backward(ctx, gx, gy, gcx, gcy, _gok, _gback, gmom, gopd, _gstk):
+        (x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, fx, fy, fcx, fcy, fok, fmom,
+         n_index) = ctx.saved_tensors
         dev = x_e.device
         F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
         S = c.numel()
         n_in = 19
-        if gx is None and gy is None and gcx is None and gcy is None and gmom is None:
+        if gopd is not None and (n_index is None or gopd.numel() == 0):
+            gopd = None
+        if gx is None and gy is None and gcx is None and gcy is None and gmom is None and gopd is None:
             return (None,) * n_in
         asph = kind_u8 is not None
         lib = _lib.lib()
         prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, ctx.allow_back, ctx.mode, kappa, poly, kind_u8,
-                        aggregate=ctx.aggregate)
+                        n_index if gopd is not None else None, aggregate=ctx.aggregate)
         ws = _workspace(lib.tl_workspace_bytes(C.byref(prob)), dev)
 
         def dense(g):
             if g is None or g.numel() == 0:
                 return None
             return _fwp(g.to(torch.float32))
-        gxd, gyd, gcxd, gcyd = dense(gx), dense(gy), dense(gcx), dense(gcy)
+        gxd, gyd, gcxd, gcyd, gopdd = dense(gx), dense(gy), dense(gcx), dense(gcy), dense(gopd)
         gmd = None if gmom is None else gmom.to(torch.float64).contiguous()
         need_xin, need_yin = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gxin = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if need_xin else None
@@ -216,6 +221,7 @@ class TraceFunction(torch.autograd.Function):
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)     # noqa: E731
         parts = [new(S), new(S), new(W, S), new(1), new(F), new(F)]
         g_kappa, g_poly = (new(S), new(S, 4)) if asph else (None, None)
+        g_n = new(W, S + 1) if gopdd is not None else None
         with torch.cuda.device(dev), _Timed("bwd", dev):
             if ctx.use_inv:
                 rc = lib.tl_trace_bwd_from_outputs(
@@ -225,9 +231,9 @@ class TraceFunction(torch.autograd.Function):
                     _lib.ptr(gyin), _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
             else:
                 rc = lib.tl_trace_bwd(C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd),
-                                      _lib.ptr(gmd), *[_lib.ptr(q) for q in parts[:6]], _lib.ptr(g_kappa),
-                                      _lib.ptr(g_poly), _lib.ptr(gxin), _lib.ptr(gyin), _lib.ptr(ws), ws.numel(),
-                                      _stream_ptr(dev))
+                                      _lib.ptr(gmd), _lib.ptr(gopdd), *[_lib.ptr(q) for q in parts[:6]], _lib.ptr(g_kappa),
+                                      _lib.ptr(g_poly), _lib.ptr(g_n), _lib.ptr(gxin), _lib.ptr(gyin), _lib.ptr(ws),
+                                      ws.numel(), _stream_ptr(dev))
         _lib.check(rc, "tl_trace_bwd")
         g_c, g_t, g_mu, g_z, g_cx, g_cy = parts
         need = ctx.needs_input_grad
@@ -241,7 +247,7 @@ class TraceFunction(torch.autograd.Function):
                 g_cy.reshape(cy.shape) if need[4] else None,
                 g_c.reshape(c.shape), g_t.reshape(t.shape), g_mu.reshape(mu.shape),
                 g_kappa.reshape(kappa.shape) if asph else None, g_poly.reshape(poly.shape) if asph else None,
-                None, None, None, None, None, None, None, None, None)
+                None, None, g_n.reshape(n_index.shape) if g_n is not None else None, None, None, None, None, None, None)
 
 
 class SpotRmsFunction(torch.autograd.Function):

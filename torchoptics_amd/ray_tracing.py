@@ -172,7 +172,8 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
                   `surf_kind` [S] (bool/int) marks the rows traced by Newton iteration -- default: the
                   rows where kappa or poly is non-zero.  Differentiable w.r.t. kappa and poly too;
       n_index, want_opd   refractive indices [1,1,1,W,S+1] (entry 0 = object space) and a seventh
-                  return value: the optical path length per ray (forward only, no gradient);
+                  return value: the optical path length per ray, differentiable w.r.t. every lens and launch
+                  parameter and w.r.t. n_index (its backward runs the checkpoint kernel);
       the returned `y` carries the fused spot moments so `compute_rms2d(x, y, ray_ok)` costs no
       second pass over the rays.
     """
