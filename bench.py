@@ -353,13 +353,13 @@ def main():
 
     # north_star sweep: 1-64 M rays x 7 / 11 / 20 rows, one field, one wavelength, fwd+bwd
     sweep = None
-    if solo and not a.no_sweep and not a.graph and a.workload == "cfg3" and a.log2_pupil is None:
+    if solo and not a.no_sweep and a.workload == "cfg3" and a.log2_pupil is None:
         sweep = []
         for lens_name, rows in (("cooke7", 7), ("dg11", 11), ("zoom20", 20)):
             log(f"sweep: {rows} rows")
             for lp in (20, 22, 24, 26):
                 j3 = Job(lens_name, device, 1, 0, None, lp, fields=(0.707,), wl=("d",))
-                t3, km3, r3 = timed(j3, a.mode, max(5, a.steps // 2), 2, 1, False, a.backend, device)
+                t3, km3, r3 = timed(j3, a.mode, max(5, a.steps // 2), 2, 1, a.graph, a.backend, device)
                 s3 = summarize(j3, t3, max(5, a.steps // 2))
                 sweep.append(dict(rows=rows, rays=j3.rays_total, value=s3["value"], ms_per_step=s3["ms_per_step"],
                                   fwd_kernel_ms=km3.get("fwd"), bwd_kernel_ms=km3.get("bwd"),
@@ -374,14 +374,16 @@ def main():
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--graph", "--steps", str(a.steps), "--warmup", str(a.warmup),
                "--repeats", str(a.repeats), "--workload", a.workload, "--mode", a.mode, "--no-cpu-baseline",
-               "--no-other-mode", "--no-sweep"]
+               "--no-other-mode"]
         if a.no_also:
             cmd += ["--no-also"]
+        if a.no_sweep:
+            cmd += ["--no-sweep"]
         if a.log2_pupil is not None:
             cmd += ["--log2-pupil", str(a.log2_pupil)]
         log("HIP-graph child process")
         try:
-            cp = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            cp = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
             if cp.returncode == 0 and line:
                 child = json.loads(line[-1])
@@ -392,6 +394,10 @@ def main():
                     if wname in also:
                         also[wname]["hip_graph_value"] = e["value"]
                         also[wname]["hip_graph_ms_per_step"] = e["ms_per_step"]
+                for e, ce in zip(sweep or [], child.get("sweep") or []):
+                    if (e["rows"], e["rays"]) == (ce["rows"], ce["rays"]):
+                        e["hip_graph_value"] = ce["value"]
+                        e["hip_graph_ms_per_step"] = ce["ms_per_step"]
             else:
                 hip_graph = dict(error=f"child exited with {cp.returncode}", stderr_tail=cp.stderr[-300:])
         except Exception as e:       # timeout or launch failure

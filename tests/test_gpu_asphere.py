@@ -129,7 +129,8 @@ def test_asphere_gradients_match_oracle_autograd(ta, algo, mode):
         got = q.grad.cpu()
         e64, noise = rel_l2(got.numpy(), g64.numpy()), rel_l2(g32.numpy(), g64.numpy())
         print(f"asphere {algo} {mode} d/d{n}: vs fp64 {e64:.2e} (oracle fp32 itself {noise:.2e})")
-        lim = tol if n not in ("z", "cy") else max(tol, 1e-3)          # launch conditions: cancellation-heavy
+        # launch conditions: cancellation-heavy, gated by the oracle's own fp32-vs-fp64 distance
+        lim = tol if n not in ("z", "cy") else max(3 * noise, 3e-5) * (1 if mode == "strict" else 10)
         assert e64 <= lim + 2 * noise, f"{algo} {mode} d/d{n}: {e64:.2e} vs oracle fp32 noise {noise:.2e}"
     # rows that are not aspheric get exactly zero kappa / poly gradient
     nz = torch.tensor(kind, dtype=torch.bool)

@@ -60,3 +60,21 @@ def test_vignetting_function_shrinks_the_traced_pupil(setup):
     assert abs(y[1].max().item() - 0.7) < 1e-6 and abs(y[1].min().item() + 0.9) < 1e-6
     out = tr.trace_rays(sp, lens)
     assert out[4].all().item()
+
+
+def test_psf_of_a_traced_fan(setup):
+    """Soft-histogram PSF (parity unpinned: TF text only) on the kernel's own outputs: unit area per channel, its
+    grid is centred on the y centroid the fused spot moments give, failed rays are left out through ray_ok."""
+    ta, lens, specs = setup
+    tr = ta.RayTracer(mode="circular", n_rays=(32, 64), rel_fields=(0., 0.7, 1.0), wavelengths=("C", "d", "F"),
+                      default_device=DEV)
+    x, y, cx, cy, ok, back = tr.trace_rays(specs, lens)
+    xs, ys, yt, k, acc = ta.metrics.psf_from_trace(x, y, ok, n_bins=(21, 21))
+    assert k.shape == (3, 3, 21, 21) and torch.isfinite(k).all()
+    assert torch.allclose(k.sum(dim=(-1, -2)), torch.ones(3, 3, device=DEV), atol=1e-5)
+    mom = y._tl_spot[0]                                     # [F, 10] fused moments of the same trace
+    assert torch.allclose(yt.double(), mom[:, 1] / mom[:, 3], rtol=1e-6, atol=1e-7)     # sum ok*y / sum ok
+    assert (acc > 0.8).all()
+    # a fixed 2 um pixel: the on-axis spot of this f/3 lens sits inside 21 pixels
+    k2 = ta.metrics.psf_from_trace(x, y, ok, n_bins=(21, 21), increment=0.002)[3]
+    assert k2[0, 1, 8:13, 8:13].sum().item() > 0.5

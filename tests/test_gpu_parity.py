@@ -291,7 +291,8 @@ def test_checkpoint_free_backward_vs_reference_autograd(ta, case, mode):
     """tl_trace_bwd_from_outputs (walk back from the forward's outputs, no checkpoints): gradients of the
     lens parameters vs the reference's autograd, and vs the checkpoint kernel, on every fixture incl. the
     failure-heavy one.  strict: 1e-5 vs fp32 autograd (or within the fp32 reference's own distance from
-    fp64); fast: 1e-4.  Launch conditions z, cy: 1e-3 (cancellation-heavy)."""
+    fp64); fast: 1e-4.  Launch conditions z, cy (residuals ~1e-3 of their per-ray terms): within
+    max(3 x the reference's own fp32-vs-fp64 distance, 3e-5) of the fp64 gradient (x10 in fast mode)."""
     from torchoptics_amd import ops
     g = load_golden(case)
     res = {}
@@ -314,9 +315,15 @@ def test_checkpoint_free_backward_vs_reference_autograd(ta, case, mode):
         if np.linalg.norm(w64) < 1e-6 * np.linalg.norm(g["gin_c64"]):     # zero by symmetry (on-axis-only fans)
             continue
         e32, e64, noise = rel_l2(gi, w32), rel_l2(gi, w64), rel_l2(w32, w64)
-        lim = tol if n in ("c", "t", "mu") else 1e-3
+        print(f"{case} {mode} d/d{n}: vs fp32 {e32:.2e} vs fp64 {e64:.2e} (reference fp32 vs fp64 {noise:.2e}) "
+              f"walk-back vs checkpoint {rel_l2(gi, gc_):.2e}")
+        if n in ("c", "t", "mu"):
+            lim, lim_ab = tol, 2e-5
+        else:
+            lim = max(3 * noise, 3e-5) * (1 if mode == "strict" else 10)
+            lim_ab = 2 * lim
         assert e32 <= lim or e64 <= max(lim, 2 * noise), f"{case} {mode} d/d{n}: vs fp32 {e32:.2e}, vs fp64 {e64:.2e}"
-        assert rel_l2(gi, gc_) <= (2e-5 if n in ("c", "t", "mu") else 2e-3), f"{case} {mode} d/d{n}: inverse vs checkpoint"
+        assert rel_l2(gi, gc_) <= lim_ab, f"{case} {mode} d/d{n}: inverse vs checkpoint"
 
 
 def test_checkpoint_free_backward_with_dense_upstream_gradients(ta):

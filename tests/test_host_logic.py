@@ -216,3 +216,25 @@ def test_gradient_free_conversions_are_memoised_safely():
     nd_g = nd.clone().requires_grad_(True)                                  # with autograd: always fresh, with a graph
     n5 = lm.Lens(st, c, t, nd_g, v).get_refractive_indices((587.6,))
     assert n5.requires_grad
+
+
+def test_memo_key_tells_aliasing_views_and_fields_apart():
+    """the cache key ignored strides and the field name.  Two gradient-free views with the same
+    first element and shape but different strides (a row and a column of one matrix) are different data, and c
+    and t padded with the same fill must never share an entry."""
+    from torchoptics_amd import lens_modeling as lm
+    # two lenses of different length, so that padding really happens (5 and 3 rows)
+    st = lm.Structure(stop_idx=np.array([2, 1]), sequence=np.array(["GAAGA", "AGA"]), default_device="cpu")
+    M = torch.arange(64, dtype=torch.float32).reshape(8, 8) + 1.0
+    row, col = M[0, :], M[:, 0]                        # same data_ptr, same shape [8], strides 1 vs 8
+    assert row.data_ptr() == col.data_ptr() and row.shape == col.shape
+    nd, v = torch.tensor([1.5, 1.6, 1.7]), torch.tensor([60.0, 40.0, 50.0])
+    a = lm.Lens(st, row, row, nd, v)
+    b = lm.Lens(st, col, col, nd, v)
+    assert torch.equal(a.c[0], row[:5]) and torch.equal(a.c[1, :3], row[5:8])
+    assert torch.equal(b.c[0], col[:5]) and torch.equal(b.c[1, :3], col[5:8])
+    assert not torch.equal(a.c, b.c)
+    # c and t from DIFFERENT tensors that happen to be padded alike: each gets its own values
+    cc, tt = torch.full((8,), 2.0), torch.full((8,), 3.0)
+    lens = lm.Lens(st, cc, tt, nd, v)
+    assert (lens.c[0] == 2.0).all() and (lens.t[0] == 3.0).all() and lens.c[1, 3:].eq(0).all()

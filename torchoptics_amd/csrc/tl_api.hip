@@ -94,8 +94,10 @@ __device__ __forceinline__ double block_sum_256(double v, double *sm)
     return sm[0];
 }
 
-// sum part[row][col] over rows = {((f*W + w)*nbx + bx)} for f in [f0,f0+nf), w in [w0,w0+nw)
-__device__ __forceinline__ double sum_rows(const double *part, int ncol, int col, int W, int nbx,
+// sum part[col][row] over rows = {((f*W + w)*nbx + bx)} for f in [f0,f0+nf), w in [w0,w0+nw); the partials are stored
+// column-major ([column][F*W*nbx blocks]), so a column is one contiguous, coalesced run (row-major measured 18-20 us
+// per reduction kernel at 8192 blocks: every output's block touched every 288-byte row)
+__device__ __forceinline__ double sum_rows(const double *part, int64_t nrows, int col, int W, int nbx,
                                            int f0, int nf, int w0, int nw, double *sm)
 {
     const int64_t n = (int64_t)nf * nw * nbx;
@@ -105,18 +107,22 @@ __device__ __forceinline__ double sum_rows(const double *part, int ncol, int col
         const int64_t r = i / nbx;
         const int w = w0 + (int)(r % nw);
         const int f = f0 + (int)(r / nw);
-        acc += part[(((int64_t)f * W + w) * nbx + bx) * ncol + col];
+        acc += part[(int64_t)col * nrows + (((int64_t)f * W + w) * nbx + bx)];
     }
     return block_sum_256(acc, sm);
 }
 
+// clear_word (nullable): the walk-back's poison word of this problem's workspace (poison_word below), cleared here
+// so that a step replayed from a HIP graph -- same token every replay -- starts clean without a memset node
 __global__ __launch_bounds__(kBlock) void reduce_moments_kernel(const double *__restrict__ part,
-                                                                double *__restrict__ mom, int W, int nbx)
+                                                                double *__restrict__ mom, int W, int nbx,
+                                                                unsigned *__restrict__ clear_word)
 {
     __shared__ double sm[kBlock];
     const int f = blockIdx.x / TL_NMOM, j = blockIdx.x % TL_NMOM;
-    const double s = sum_rows(part, TL_NMOM, j, W, nbx, f, 1, 0, W, sm);
+    const double s = sum_rows(part, (int64_t)(gridDim.x / TL_NMOM) * W * nbx, j, W, nbx, f, 1, 0, W, sm);
     if (threadIdx.x == 0) mom[blockIdx.x] = s;
+    if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
 }
 
 __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__restrict__ part, int NS, int F,
@@ -161,7 +167,8 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
         const int w = b / (S + 1), k = b % (S + 1);
         col = (g_kappa ? 8 : 3) * NS + 3 + k; w0 = w; nw = 1; out = g_n + b;
     }
-    const double s = sum_rows(part, ncol, col, W, nbx, f0, nf, w0, nw, sm);
+    (void)ncol;
+    const double s = sum_rows(part, (int64_t)F * W * nbx, col, W, nbx, f0, nf, w0, nw, sm);
     if (threadIdx.x == 0) *out = (float)s;        // summed in fp64, rounded once
 }
 
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void spot_moments_kernel(int P, int W, cons
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < kBlock / 64; ++q) s += red[q][threadIdx.x];
-        part[((size_t)fw * gridDim.x + blockIdx.x) * TL_NMOM + threadIdx.x] = s;
+        part[(size_t)threadIdx.x * ((size_t)gridDim.y * gridDim.x) + ((size_t)fw * gridDim.x + blockIdx.x)] = s;   // [column][block]
     }
 }
 
@@ -307,6 +314,13 @@ const char *tl_last_error(void) { return g_err; }
 
 size_t tl_problem_size(void) { return sizeof(tl_problem); }
 
+// The walk-back kernel's poison word lives in the slack at the END of the workspace this problem asks for (the
+// last 256 bytes belong to no partial array), at an address tl_trace_fwd can compute as well.
+static unsigned *poison_word(const tl_problem *p, void *workspace)
+{
+    return (unsigned *)((char *)workspace + tl_workspace_bytes(p) - 64);
+}
+
 size_t tl_workspace_bytes(const tl_problem *p)
 {
     if (!p || p->F < 1 || p->W < 1 || p->S < 1 || p->P < 0) return 0;
@@ -350,7 +364,8 @@ int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, 
                                          : tl_strict::api_fwd(q, x, y, cx, cy, ok, back, opd, stacks, part, pl.nbx, pl.R, st);
     if (herr) return hip_fail(herr, "trace_fwd_kernel launch");
     if (moments) {
-        hipLaunchKernelGGL(reduce_moments_kernel, dim3(p->F * TL_NMOM), dim3(kBlock), 0, st, part, moments, p->W, pl.nbx);
+        unsigned *clear = (workspace_bytes >= tl_workspace_bytes(p)) ? poison_word(p, workspace) : nullptr;
+        hipLaunchKernelGGL(reduce_moments_kernel, dim3(p->F * TL_NMOM), dim3(kBlock), 0, st, part, moments, p->W, pl.nbx, clear);
         herr = (int)hipGetLastError();
         if (herr) return hip_fail(herr, "reduce_moments_kernel launch");
     }
@@ -429,22 +444,15 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     const int ncol = (asph ? 8 : 3) * p->S + 3, ns = tl_bwd_bucket(p->S), ncol_ck = tl_bwd_row(ns, asph);
     const size_t rows = (size_t)p->F * p->W * pl.nbx, rows_ck = (size_t)p->F * p->W * pk.nbx;
     const size_t need_inv = rows * ncol * sizeof(double), need_ck = rows_ck * ncol_ck * sizeof(double);
-    if (!workspace || workspace_bytes < need_inv + need_ck + sizeof(double))
+    if (!workspace || workspace_bytes < tl_workspace_bytes(p) || tl_workspace_bytes(p) < need_inv + need_ck + 256)
         return fail(TL_EWORKSPACE, "workspace too small for tl_trace_bwd_from_outputs");
     double *part = (double *)workspace, *part_ck = part + rows * ncol;
-    unsigned *poison = (unsigned *)(part_ck + rows_ck * ncol_ck);      // the walk-back writes `token` here on a non-finite adjoint
+    unsigned *poison = poison_word(p, workspace);      // the walk-back writes `token` here on a non-finite adjoint
     static std::atomic<uint32_t> calls{0};
     uint32_t token = (calls.fetch_add(1u) + 1u) * 0x9E3779B1u;         // unique per call, nothing like stale data
     if (token == 0u) token = 1u;
-    {
-        // Recorded into a HIP graph, this call is replayed with the SAME token every time: a word poisoned by
-        // one replay would send every later replay to the checkpoint kernel (exact, but slower, silently).  So
-        // under capture -- and only there, a memset node costs ~6 us -- the word is cleared first.
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
-            if ((e = hipMemsetAsync(poison, 0, sizeof(unsigned), st)) != hipSuccess) return hip_fail(e, "hipMemsetAsync(poison)");
-        }
-    }
+    // (Recorded into a HIP graph the call is replayed with the SAME token every time; the word is cleared by the
+    //  forward call of the same step, see reduce_moments_kernel, so a poisoned replay does not stick.)
     int herr = (p->mode == TL_MODE_FAST)
                    ? tl_fast::api_bwd_inv(*p, gx, gy, gcx, gcy, g_moments, x_fwd, y_fwd, cx_fwd, cy_fwd, ok_fwd,
                                           moments_fwd, g_x_in, g_y_in, part, part_ck, poison, token, pl.nbx, pl.R, pk.nbx, pk.R, st)
@@ -477,7 +485,7 @@ int tl_spot_moments(int32_t device, int32_t F, int32_t P, int32_t W, const float
     int herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "spot_moments_kernel launch");
     hipLaunchKernelGGL(reduce_moments_kernel, dim3(F * TL_NMOM), dim3(kBlock), 0, st, (const double *)workspace,
-                       moments, W, pl.nbx);
+                       moments, W, pl.nbx, (unsigned *)nullptr);
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_moments_kernel launch");
     return TL_OK;

@@ -191,7 +191,10 @@ def _memoised(tag, extra, key_tensors, grad_tensors, fn):
     in autograd (the result then carries a graph and must be fresh)."""
     if any(t.requires_grad for t in grad_tensors):
         return fn()
-    key = (tag, extra) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device) for t in key_tensors)
+    # identity of a tensor's CONTENTS: storage address, layout (two views with the same first element and shape but
+    # different strides -- M[0, :] and M[:, 0] -- are different data), version counter, dtype, device
+    key = (tag, extra) + tuple((t.data_ptr(), t.storage_offset(), tuple(t.stride()), t._version, tuple(t.shape), t.dtype,
+                                t.device) for t in key_tensors)
     hit = _memo.get(key)
     if hit is None or hit[0]._version != hit[1]:         # never computed, or somebody wrote into the cached result
         if len(_memo) > 64:
@@ -203,8 +206,9 @@ def _memoised(tag, extra, key_tensors, grad_tensors, fn):
     return hit[0]
 
 
-def _pad_from_flat(flat: torch.Tensor, mask_t: torch.Tensor, fill: float, idx: torch.Tensor) -> torch.Tensor:
-    """flat [n] (or [n, k]) -> padded [lens, row] (or [lens, row, k]) with `fill` elsewhere."""
+def _pad_from_flat(flat: torch.Tensor, mask_t: torch.Tensor, fill: float, idx: torch.Tensor, what: str = "") -> torch.Tensor:
+    """flat [n] (or [n, k]) -> padded [lens, row] (or [lens, row, k]) with `fill` elsewhere.  `what` names the
+    field (c, t, nd ...): part of the memo key, so two fields padded alike never share an entry."""
     tail = tuple(flat.shape[1:])
     flat = flat.to(mask_t.device)
     if idx.numel() == mask_t.numel():            # nothing to pad (one lens, or equal-length lenses): a view
@@ -213,7 +217,7 @@ def _pad_from_flat(flat: torch.Tensor, mask_t: torch.Tensor, fill: float, idx: t
     def pad():
         base = torch.full((mask_t.numel(), *tail), fill, dtype=flat.dtype, device=mask_t.device)
         return base.index_copy(0, idx, flat).reshape(*mask_t.shape, *tail)
-    return _memoised("pad", (fill if fill == fill else "nan", tuple(mask_t.shape)), (flat, idx), (flat,), pad)
+    return _memoised("pad", (what, fill if fill == fill else "nan", tuple(mask_t.shape)), (flat, idx), (flat,), pad)
 
 
 def _take(padded: torch.Tensor, width: int, idx: torch.Tensor) -> torch.Tensor:
@@ -248,17 +252,17 @@ class Lens:
                 self.poly = torch.zeros(n_rows, 4, dtype=ref.dtype, device=ref.device)
         if self.kappa is not None:
             if self.kappa.dim() == 1:
-                self.kappa = _pad_from_flat(self.kappa, st.mask_torch, 0.0, st.idx_rows)
+                self.kappa = _pad_from_flat(self.kappa, st.mask_torch, 0.0, st.idx_rows, "kappa")
             if self.poly.dim() == 2:                 # flat [rows, 4] -> padded [lens, row, 4]
-                self.poly = _pad_from_flat(self.poly, st.mask_torch, 0.0, st.idx_rows)
+                self.poly = _pad_from_flat(self.poly, st.mask_torch, 0.0, st.idx_rows, "poly")
         if self.c.dim() == 1:
-            self.c = _pad_from_flat(self.c, st.mask_torch, 0.0, st.idx_rows)
+            self.c = _pad_from_flat(self.c, st.mask_torch, 0.0, st.idx_rows, "c")
         if self.t.dim() == 1:
-            self.t = _pad_from_flat(self.t, st.mask_torch, 0.0, st.idx_rows)
+            self.t = _pad_from_flat(self.t, st.mask_torch, 0.0, st.idx_rows, "t")
         if self.nd.dim() == 1:
-            self.nd = _pad_from_flat(self.nd, st.mask_G_torch, 1.0, st.idx_glass)
+            self.nd = _pad_from_flat(self.nd, st.mask_G_torch, 1.0, st.idx_glass, "nd")
         if self.v.dim() == 1:
-            self.v = _pad_from_flat(self.v, st.mask_G_torch, float('nan'), st.idx_glass)
+            self.v = _pad_from_flat(self.v, st.mask_G_torch, float('nan'), st.idx_glass, "v")
 
     def __len__(self):
         return len(self.structure)

@@ -76,3 +76,77 @@ def compute_ray_aiming_error(specs, lens, rel_fields, vig_fn=None, n_ray_aiming_
         fields = torch.tensor(list(rel_fields), dtype=torch.float32, device=default_device)[None, :]
         y = apply_vignetting(y, vig_fn(fields, specs.vig_up), vig_fn(fields, specs.vig_down))
     return ys / rs - y
+
+
+def compute_psf(x, y, n_bins=(21, 21), increment=None, y_target=None, weights=None):
+    """Soft-histogram PSF of a ray fan on a per-field pixel grid (the reference's TensorFlow
+    `compute_psf`, ray_tracing.py:206-270; unreachable in its PyTorch port, PARITY UNPINNED).
+
+    x, y: [n_lens, n_fields, n_channels, n_rays] image-plane coordinates (`psf_from_trace` brings the
+    tracer's [1,F,P,W] outputs into this layout).  One grid per (lens, field), centred at x = 0 and
+    y = y_target (default: the mean y of the field); pixel size `increment`, or the fan's extent / n_bins.
+    Every ray adds a Gaussian of sigma = half a pixel to each pixel centre; as in the reference only the
+    x >= 0 half of the grid is evaluated and mirrored (the pupil is sampled symmetrically in x), and each
+    channel's kernel is normalised to unit sum.
+    `weights` (extension; same shape as x): per-ray weights, e.g. ray_ok as float to leave failed rays out.
+
+    Returns (x_size, y_size, y_target, kernels [n_grids, n_channels, n_y_bins, n_x_bins],
+    accounted_ray_proportion [n_grids]).
+
+    The double sum over rays and pixels is a contraction over the ray index, so it is evaluated as one batched
+    GEMM  G_y [ny, R] @ G_x^T [R, nx]  per (grid, channel) instead of the reference's [.., ny, nx, R] tensor.
+    """
+    nw, nr = x.shape[-2], x.shape[-1]
+    n_grids = x.shape[0] * x.shape[1]
+    n_x_bins, n_y_bins = n_bins
+    x = x.reshape(n_grids, nw, nr)
+    y = y.reshape(n_grids, nw, nr)
+    if y_target is None:
+        y_target = y.reshape(n_grids, -1).mean(dim=1)
+    y = y - y_target[:, None, None]
+    if increment is not None:
+        x_incr = y_incr = torch.ones(n_grids, dtype=x.dtype, device=x.device) * increment
+        x_size = increment * n_x_bins
+        y_size = increment * n_x_bins                  # (sic: the reference uses n_x_bins for both)
+    else:
+        flat_y = y.reshape(n_grids, -1)
+        y_c_min, y_c_max = flat_y.min(dim=1).values, flat_y.max(dim=1).values      # y is centred already
+        x_size = x.reshape(n_grids, -1).max(dim=1).values
+        y_size = 2 * torch.maximum(y_c_max, -y_c_min)
+        x_incr = x_size / n_x_bins
+        y_incr = y_size / n_y_bins
+    rng = lambda n: torch.arange(n, dtype=x.dtype, device=x.device)                 # noqa: E731
+    if n_x_bins % 2 == 1:
+        gx = rng(n_x_bins // 2 + 1)[None, :] * x_incr[:, None]
+    else:
+        gx = (rng(n_x_bins // 2) + 0.5)[None, :] * x_incr[:, None]
+    gy = (rng(n_y_bins) + 0.5 - n_y_bins / 2)[None, :] * y_incr[:, None]
+    sig_x, sig_y = (x_incr / 2)[:, None, None, None], (y_incr / 2)[:, None, None, None]
+    g_x = torch.exp(-((x[:, :, None, :] - gx[:, None, :, None]) / sig_x) ** 2 / 2)   # [g, w, nx_half, r]
+    g_y = torch.exp(-((y[:, :, None, :] - gy[:, None, :, None]) / sig_y) ** 2 / 2)   # [g, w, ny, r]
+    if weights is not None:
+        g_y = g_y * weights.reshape(n_grids, nw, 1, nr).to(g_y.dtype)
+    kernels = torch.matmul(g_y, g_x.transpose(-1, -2))                               # [g, w, ny, nx_half]
+    if n_x_bins % 2 == 1:
+        kernels = torch.cat((torch.flip(kernels[..., 1:], dims=(-1,)), kernels), dim=-1)
+    else:
+        kernels = torch.cat((torch.flip(kernels, dims=(-1,)), kernels), dim=-1)
+    kernels = kernels / kernels.sum(dim=(-1, -2), keepdim=True)
+    xs = x_size if torch.is_tensor(x_size) else torch.full((n_grids,), float(x_size), dtype=x.dtype, device=x.device)
+    ys = y_size if torch.is_tensor(y_size) else torch.full((n_grids,), float(y_size), dtype=x.dtype, device=x.device)
+    accounted = (y.abs() < ys[:, None, None] / 2) & (x.abs() < xs[:, None, None] / 2)
+    return x_size, y_size, y_target, kernels, accounted.to(x.dtype).mean(dim=(-1, -2))
+
+
+def psf_from_trace(x, y, ray_ok=None, n_bins=(21, 21), increment=None, y_target=None):
+    """compute_psf on the outputs of RayTracer.trace_rays / trace_skew ([1, F, P, W]; their memory is already
+    [F, W, P], so the permutation below is free).  With `ray_ok` failed rays are left out of the histogram and of
+    the default y_target (the reference counts them as rays at the origin)."""
+    xt, yt = x.permute(0, 1, 3, 2), y.permute(0, 1, 3, 2)
+    w = None
+    if ray_ok is not None:
+        w = ray_ok.permute(0, 1, 3, 2).to(y.dtype)
+        if y_target is None:
+            n_g = yt.shape[0] * yt.shape[1]
+            y_target = (yt * w).reshape(n_g, -1).sum(dim=1) / w.reshape(n_g, -1).sum(dim=1).clamp_min(1)
+    return compute_psf(xt, yt, n_bins=n_bins, increment=increment, y_target=y_target, weights=w)

@@ -237,9 +237,9 @@ class TraceFunction(torch.autograd.Function):
         _lib.check(rc, "tl_trace_bwd")
         g_c, g_t, g_mu, g_z, g_cx, g_cy = parts
         need = ctx.needs_input_grad
-        if need[3] and cx.numel() == 1:
+        if need[3] and cx.numel() == 1 and F > 1:
             g_cx = g_cx.sum(dim=0, keepdim=True)
-        if need[4] and cy.numel() == 1:
+        if need[4] and cy.numel() == 1 and F > 1:
             g_cy = g_cy.sum(dim=0, keepdim=True)
         return (gxin.permute(0, 1, 3, 2) if need_xin else None,
                 gyin.permute(0, 1, 3, 2) if need_yin else None,
@@ -271,7 +271,7 @@ class SpotRmsFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dm,) = ctx.saved_tensors
-        return dm * g.to(torch.float64), None
+        return dm * g, None          # [F,10] fp64 * 0-dim fp32 -> fp64 in one launch (no separate cast)
 
 
 class SpotMomentsFunction(torch.autograd.Function):

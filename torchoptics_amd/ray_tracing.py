@@ -160,8 +160,9 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
     """Trace rays from the entrance pupil to the image plane through S surface rows.
 
     Same contract as the reference (ray_tracing_lite.py:594-675): inputs broadcast to
-    [1, F, P, W]; returns (x, y, cx, cy, ray_ok, ray_backward).  Differentiable w.r.t.
-    x, y, z, cx, cy, c, t, mu through a hand-written backward kernel.
+    [B, F, P, W]; returns (x, y, cx, cy, ray_ok, ray_backward).  Differentiable w.r.t.
+    x, y, z, cx, cy, c, t, mu through a hand-written backward kernel.  B > 1 padded lenses run
+    as one launch per lens (`_trace_skew_batch`); aggregate=True is built for B = 1 only.
 
     Extras (not in the reference):
       aggregate   True: a 7th return value `stacks` = {'z_RELU', 'theta_norm', 'theta_prime_norm'}, each a
@@ -177,6 +178,10 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
       the returned `y` carries the fused spot moments so `compute_rms2d(x, y, ray_ok)` costs no
       second pass over the rays.
     """
+    n_lens = max(a.shape[0] for a in (x, y, z, cx, cy, c, t, mu, mask) if torch.is_tensor(a) and a.dim() >= 4)
+    if n_lens > 1:
+        return _trace_skew_batch(n_lens, x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays, mode, want_rays,
+                                 kappa, poly, surf_kind, n_index, want_opd)
     x, y, z, cx, cy = (_as_f32(a, n) for a, n in ((x, 'x'), (y, 'y'), (z, 'z'), (cx, 'cx'), (cy, 'cy')))
     c, t, mu = _as_f32(c, 'c'), _as_f32(t, 't'), _as_f32(mu, 'mu')
     for a, n in ((x, 'x'), (y, 'y'), (cx, 'cx'), (cy, 'cy'), (z, 'z')):
@@ -226,6 +231,34 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
             res += (PenaltyStacks(stk, moments),)
         return res
     return moments
+
+
+def _trace_skew_batch(n_lens, x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays, mode, want_rays, kappa,
+                      poly, surf_kind, n_index, want_opd):
+    """B > 1 padded lenses (the reference's `trace_skew` broadcasts over dim 0; its callers only ever pass B = 1,
+    SURVEY 0.4): one kernel launch per lens on that lens' slice of every argument, outputs concatenated along
+    dim 0.  Padded rows (c = 0, t = 0, mu = 1, mask False) are identity rows.  The fused spot moments of LENS 0 stay
+    attached to `y`, because compute_rms2d reads sample 0 only (ray_tracing_lite.py:695,699)."""
+    if aggregate or not want_rays:
+        raise NotImplementedError("aggregate=True / want_rays=False are built for a single lens (B = 1)")
+
+    def pick(a, b, lens_dims):
+        # per-lens slice of an argument whose leading dim is the lens axis (size 1 = shared by all lenses)
+        if a is None or not torch.is_tensor(a) or a.dim() < lens_dims:
+            return a
+        return a[b:b + 1] if a.shape[0] == n_lens else a
+    outs = []
+    for b in range(n_lens):
+        kap = None if kappa is None else (kappa[b] if kappa.dim() == 2 else kappa)
+        pol = None if poly is None else (poly[b] if poly.dim() == 3 else poly)
+        kind = None if surf_kind is None else (surf_kind[b] if torch.is_tensor(surf_kind) and surf_kind.dim() == 2 else surf_kind)
+        outs.append(trace_skew(pick(x, b, 4), pick(y, b, 4), pick(z, b, 4), pick(cx, b, 4), pick(cy, b, 4), pick(c, b, 5),
+                               pick(t, b, 5), pick(mu, b, 5), pick(mask, b, 5), False, allow_backward_rays, mode, True,
+                               kap, pol, kind, pick(n_index, b, 5), want_opd))
+    res = tuple(torch.cat([o[i] for o in outs], dim=0) for i in range(len(outs[0])))
+    tag0 = outs[0][1]._tl_spot
+    res[1]._tl_spot = (tag0[0], res[4], res[1]._version, tag0[3])
+    return res
 
 
 class PenaltyStacks(dict):
@@ -281,6 +314,8 @@ def compute_rms2d(x, y, ray_ok, group=None, n_per_field: Optional[int] = None):
     if tag is not None and tag[1] is ray_ok and tag[2] == y._version:
         moments, n_local = tag[0], tag[3]
     else:
+        if y.shape[0] > 1:                       # the reference reads sample 0 only (:695,699)
+            x, y, ray_ok = (None if x is None else x[:1]), y[:1], ray_ok[:1]
         moments = ops.SpotMomentsFunction.apply(x, y, ray_ok)
         n_local = y.shape[2] * y.shape[3]
     if group is not None:
