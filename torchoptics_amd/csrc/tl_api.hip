@@ -82,32 +82,29 @@ int check_problem(const tl_problem *p)
 }
 
 // ---------------------------------------------------------------- fixed-order reductions
+// 256 values -> one: wave sums by shuffles, then the four wave sums in a fixed order (bitwise reproducible)
 __device__ __forceinline__ double block_sum_256(double v, double *sm)
 {
-    sm[threadIdx.x] = v;
-    __syncthreads();
 #pragma unroll
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-        __syncthreads();
-    }
-    return sm[0];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 
-// sum part[col][row] over rows = {((f*W + w)*nbx + bx)} for f in [f0,f0+nf), w in [w0,w0+nw); the partials are stored
-// column-major ([column][F*W*nbx blocks]), so a column is one contiguous, coalesced run (row-major measured 18-20 us
-// per reduction kernel at 8192 blocks: every output's block touched every 288-byte row)
+// sum part[col][row] over rows = {((f*W + w)*nbx + bx)} for f in [f0,f0+nf), w in [w0,w0+nw), nw == W or nw == 1.
+// The partials are stored column-major ([column][F*W*nbx blocks]) and the rows of one f (all w, or one w) are one
+// contiguous run: coalesced reads, no index arithmetic in the loop (the first version spent its 18-20 us per
+// launch on two 64-bit divisions per element).
 __device__ __forceinline__ double sum_rows(const double *part, int64_t nrows, int col, int W, int nbx,
                                            int f0, int nf, int w0, int nw, double *sm)
 {
-    const int64_t n = (int64_t)nf * nw * nbx;
+    const double *colp = part + (int64_t)col * nrows;
+    const int count = nw * nbx;
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += kBlock) {
-        const int bx = (int)(i % nbx);
-        const int64_t r = i / nbx;
-        const int w = w0 + (int)(r % nw);
-        const int f = f0 + (int)(r / nw);
-        acc += part[(int64_t)col * nrows + (((int64_t)f * W + w) * nbx + bx)];
+    for (int f = f0; f < f0 + nf; ++f) {
+        const double *run = colp + ((int64_t)f * W + w0) * nbx;
+        for (int i = threadIdx.x; i < count; i += kBlock) acc += run[i];
     }
     return block_sum_256(acc, sm);
 }
