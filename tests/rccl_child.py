@@ -47,11 +47,15 @@ def main():
 
     l0, g0 = step(None)
     l1, g1 = step(group)
+    tl_dist.set_collective("allgather")           # the one-hop shape of the same two exchanges
+    l2, g2 = step(group)
+    tl_dist.set_collective("allreduce")
     torch.cuda.synchronize()
     dist.barrier(group)
     out = dict(backend=dist.get_backend(group), world=dist.get_world_size(group), n_ranks_seen=n_seen,
                loss_plain=float(l0), loss_dist=float(l1), loss_bitwise_equal=bool(torch.equal(l0, l1)),
                grads_bitwise_equal=bool(all(torch.equal(a, b) for a, b in zip(g0, g1))),
+               allgather_bitwise_equal=bool(torch.equal(l0, l2) and all(torch.equal(a, b) for a, b in zip(g0, g2))),
                grad_norms=[float(g.norm()) for g in g1])
     dist.destroy_process_group()
     print(json.dumps(out))

@@ -57,7 +57,7 @@ def _leaves():
     return [torch.tensor(d[k], dtype=torch.float64, requires_grad=True) for k in ("c", "t", "nd", "v")]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, collective="allreduce"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -65,6 +65,7 @@ def _worker(rank, world, port, out_dir):
     torch.set_default_dtype(torch.float64)
     torch.set_num_threads(1)
     from torchoptics_amd import dist as tl_dist, ray_tracing as rt
+    tl_dist.set_collective(collective)
     total = N_R * N_THETA
     a, b = tl_dist.shard_range(total, rank, world)
     xy = rt.circle_index_range(N_R, N_THETA, a, b, "cpu")
@@ -89,9 +90,11 @@ def test_shard_range_covers_everything_once():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharded_loss_and_grads_equal_unsharded(tmp_path, monkeypatch):
+@pytest.mark.parametrize("collective", ["allreduce", "allgather"])
+def test_two_rank_sharded_loss_and_grads_equal_unsharded(tmp_path, monkeypatch, collective):
+    """Both shapes of the two exchanges: one all-reduce each (default), or all-gather + local sum in rank order."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), collective), nprocs=2, join=True)
     res = [torch.load(tmp_path / f"rank{r}.pt", weights_only=True) for r in range(2)]
     assert res[0]["shard"] == (0, 204) and res[1]["shard"] == (204, 408)
 

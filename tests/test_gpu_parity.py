@@ -405,6 +405,62 @@ def test_walk_back_non_finite_adjoint_falls_back_to_checkpoint_kernel(ta):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def test_a_poisoned_graph_replay_does_not_stick(ta):
+    """recorded into a HIP graph the walk-back call is replayed with the same token every time, so one
+    poisoned replay (non-finite adjoint -> checkpoint fallback) would have sent every later replay to the fallback
+    as well.  The forward's reduction kernel now clears the word.  Captured step = forward, a multiply of one live
+    ray's saved x by a device scalar m, backward.  Replay with m = NaN -> the checkpoint kernel's gradients; replay
+    with m = 1 -> the walk-back kernel's again (bit-equal to the eager walk-back step, and different bits from the
+    checkpoint algorithm's)."""
+    from torchoptics_amd import ops
+    g = load_golden("G4_tessar_32x32")
+    ins, mask, allow = dev_inputs(g)
+    lv = [ins[i].clone().requires_grad_(True) for i in (5, 6, 7)]
+    m = torch.ones((), device=DEV)
+
+    def step():
+        for q in lv:
+            q.grad = None
+        x, y, cx, cy, ok, back = ta.trace_skew(*ins[:5], *lv, mask, False, allow)
+        loss = ta.compute_rms2d(x, y, ok)
+        buf = x.data.permute(0, 1, 3, 2).view(-1)              # the [1,F,W,P] buffer the backward reads
+        buf[live] = buf[live] * m
+        loss.backward()
+    with torch.no_grad():
+        ok0 = ta.trace_skew(*ins[:5], *[q.detach() for q in lv], mask, False, allow)[4]
+    live = torch.nonzero(ok0.permute(0, 1, 3, 2).reshape(-1))[7]
+    ref = {}
+    for algo in ("inverse", "checkpoint"):
+        ops.set_backward_algorithm(algo)
+        try:
+            step()
+            ref[algo] = [q.grad.clone() for q in lv]
+        finally:
+            ops.set_backward_algorithm("inverse")
+    assert not all(torch.equal(a, b) for a, b in zip(ref["inverse"], ref["checkpoint"]))     # distinguishable
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(cap)
+    for q in lv:
+        q.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=cap):
+        step()
+    m.fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip([q.grad for q in lv], ref["checkpoint"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)          # poisoned replay: the fallback did the work
+    m.fill_(1.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip([q.grad for q in lv], ref["inverse"]):
+        assert torch.equal(a, b)                                      # clean replay: the walk-back kernel again
+
+
 @pytest.mark.parametrize("wl", ["cfg3", "cfg3a", "cfg5"])
 def test_full_size_properties(ta, wl):
     """BASELINE's configurations at full size (cfg3: 2^24 rays, 11 rows; cfg3a: the same with two aspheric rows;

@@ -30,6 +30,7 @@ def test_one_rank_rccl_step_is_bitwise_the_plain_step():
     assert out["backend"] == "nccl" and out["world"] == 1 and out["n_ranks_seen"] == 1
     assert out["loss_bitwise_equal"], out
     assert out["grads_bitwise_equal"], out
+    assert out["allgather_bitwise_equal"], out        # all-gather + fixed-order local sum: the same bits
     assert all(g > 0 for g in out["grad_norms"])
 
 

@@ -74,7 +74,7 @@ def _build(OBJ, LIB, extra_flags, force, verbose):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     deps = [os.path.normpath(os.path.join(CSRC, d)) for d in DEPS]
-    objs, rebuilt = [], False
+    objs, jobs = [], []
     for src, extra in UNITS.items():
         spath = os.path.join(CSRC, src)
         opath = os.path.join(OBJ, src.replace(".hip", ".o"))
@@ -84,14 +84,21 @@ def _build(OBJ, LIB, extra_flags, force, verbose):
         fresh = (not force and os.path.exists(opath) and os.path.exists(stamp)
                  and open(stamp).read() == dig)
         if not fresh:
-            cmd = [hipcc] + flags + ["-c", spath, "-o", opath]
-            if verbose:
-                print("[tltrace]", " ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
-            with open(stamp, "w") as f:
-                f.write(dig)
-            rebuilt = True
+            jobs.append(([hipcc] + flags + ["-c", spath, "-o", opath], stamp, dig))
         objs.append(opath)
+
+    def compile_one(job):
+        cmd, stamp, dig = job
+        if verbose:
+            print("[tltrace]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        with open(stamp, "w") as f:
+            f.write(dig)
+    if jobs:        # the translation units are independent: compile them side by side (each hipcc is one process)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 3)) as pool:
+            list(pool.map(compile_one, jobs))
+    rebuilt = bool(jobs)
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

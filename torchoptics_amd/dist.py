@@ -14,6 +14,7 @@ same closed form on the same summed moments), so the backward of #1 is the ident
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, Tuple
 
 import torch
@@ -61,12 +62,40 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+# How the two < 2 KB exchanges are done.  "allreduce": one RCCL all-reduce (default).  "allgather": the shape
+# SURVEY 8e prefers on a fully connected xGMI node -- every rank sends its partial vector to every peer in one hop
+# (all-gather), then sums the N vectors locally in rank order: latency-optimal for tiny messages, and the result is
+# bitwise identical on every rank and from run to run by construction, whatever the collective's internal algorithm.
+_collective = os.environ.get("TORCHOPTICS_AMD_COLLECTIVE", "allreduce")
+
+
+def set_collective(name: str) -> None:
+    global _collective
+    if name not in ("allreduce", "allgather"):
+        raise ValueError("collective must be 'allreduce' or 'allgather'")
+    _collective = name
+
+
+def get_collective() -> str:
+    return _collective
+
+
+def _sum_over_ranks(t: torch.Tensor, group) -> torch.Tensor:
+    """New tensor = sum of `t` over the ranks of `group` (t itself is left untouched)."""
+    if _collective == "allgather":
+        world = dist.get_world_size(group)
+        buf = t.new_empty((world,) + tuple(t.shape))
+        dist.all_gather(list(buf.unbind(0)), t.contiguous(), group=group)      # views of one buffer, rank order
+        return buf.sum(dim=0)
+    out = t.clone()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    return out
+
+
 class _AllReduceSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, group):
-        out = t.clone()
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
-        return out
+        return _sum_over_ranks(t, group)
 
     @staticmethod
     def backward(ctx, g):
@@ -90,9 +119,7 @@ def all_reduce_grads(params: Iterable[torch.Tensor], group=None) -> None:
         return
     grads = [p.grad for p in params]
     # four launches + one collective, whatever the number of leaves: cat, widen, all-reduce, narrow, scatter back
-    flat = torch.cat([g.reshape(-1) for g in grads]).to(torch.float64)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat = flat.to(grads[0].dtype)
+    flat = _sum_over_ranks(torch.cat([g.reshape(-1) for g in grads]).to(torch.float64), group).to(grads[0].dtype)
     views, off = [], 0
     for g in grads:
         n = g.numel()
