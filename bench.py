@@ -403,6 +403,26 @@ def main():
         except Exception as e:       # timeout or launch failure
             hip_graph = dict(error=repr(e))
 
+    # BASELINE configs[4]: the 100-step Adam loop on the 20-row zoom (5 fields x 3 wavelengths, 2^20 pupil points per
+    # GPU), every step = Lens assembly + dispersion + pupil position + forward + RMS + backward + Adam; eager and with
+    # the whole step replayed from a HIP graph (child processes: examples/adam_loop.py is the harness)
+    if solo and group is None and not a.graph and not a.no_also and a.workload == "cfg3" and a.log2_pupil is None:
+        import subprocess
+        log("cfg5 Adam loop (child processes)")
+        adam = {}
+        for tag, flags in (("eager", []), ("hip_graph", ["--graph"])):
+            try:
+                cp = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "adam_loop.py"), "--steps", "100",
+                                     "--log2-pupil", "20", "--mode", a.mode] + flags, capture_output=True, text=True, timeout=240)
+                line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                r = json.loads(line[-1]) if cp.returncode == 0 and line else None
+                adam[tag] = (dict(steps_per_s=r["steps_per_s"], M_rays_per_s=r["M_rays_per_s"], loss_initial=r["loss_initial"],
+                                  loss_final=r["loss_final"]) if r else dict(error=f"exit {cp.returncode}", stderr_tail=cp.stderr[-300:]))
+            except Exception as e:
+                adam[tag] = dict(error=repr(e))
+        also["cfg5_adam_loop"] = dict(workload="20-row zoom, F=5 W=3 P=2^20 (15.7 M rays per step), 100 Adam steps on c and t, "
+                                               "1 GPU; steps include the whole host chain", arith_mode=a.mode, **adam)
+
     cpu_baseline, grad_check, leaf_grads = None, None, None
     if rank == 0 and solo and not a.no_cpu_baseline:
         log("cpu baseline + gradient check")
