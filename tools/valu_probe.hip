@@ -4,8 +4,10 @@
 //
 // Every lane runs `chains` independent dependency chains of one operation for `iters` rounds; occupancy (waves per
 // SIMD) is set by the dynamic LDS size of the 256-thread blocks (one wave per SIMD each) on a grid of exactly
-// 256 CUs x waves blocks.  Prints SIMD cycles per wave-instruction at the clock measured with s_memtime /
-// s_memrealtime, i.e. the inverse issue rate: 2.0 = the VALU peak (one wave64 instruction per 2 cycles).
+// 256 CUs x waves blocks.  Prints SIMD cycles per wave-instruction = wall time of the launch (HIP events) x the
+// in-kernel clock (s_memtime / s_memrealtime) / instructions per SIMD: 2.0 = the VALU peak (one wave64 instruction
+// per 2 cycles).  The chains are written in C, so which operands sit in SGPRs is the compiler's choice (the MIX_ROW
+// FMAs read one: that is the half-rate case of valu_probe2.hip).
 // Development tool (DESIGN.md section 4 "what bounds the walk-back kernel"), not part of the product.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void probe(float *out, int iters, float a, flo
 template <int OP, int CHAINS>
 static void run(const char *name, int instr_per_step, float *out, unsigned long long *clk)
 {
-    const int iters = 2000;
+    const int iters = 20000;
     for (int waves : {1, 2, 3, 4, 5, 6, 8}) {
         const size_t lds = (160 * 1024) / waves - 1024;
         hipFuncSetAttribute((const void *)probe<OP, CHAINS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -79,7 +81,7 @@ static void run(const char *name, int instr_per_step, float *out, unsigned long 
         hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
         const double ghz = (double)h[0] / ((double)h[1] * 10.0);       // s_memrealtime ticks at 100 MHz
         const double winstr = (double)iters * 8 * CHAINS * instr_per_step * waves;     // wave-instructions per SIMD
-        const double cyc = (double)h[0] / winstr;                                      // in-kernel cycles of block 0
+        const double cyc = ms * 1e-3 * ghz * 1e9 / winstr;                             // wall time x in-kernel clock
         printf("%-12s chains %d waves/SIMD %d : %6.2f cycles per wave-instruction  (%.3f ms, in-kernel clock %.2f GHz)\n", name,
                CHAINS, waves, cyc, ms, ghz);
     }
