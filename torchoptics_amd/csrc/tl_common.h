@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/tl_trace.h"
 
 // compile-time surface-row buckets of the backward kernel

@@ -80,14 +80,14 @@ def get_collective() -> str:
     return _collective
 
 
-def _sum_over_ranks(t: torch.Tensor, group) -> torch.Tensor:
-    """New tensor = sum of `t` over the ranks of `group` (t itself is left untouched)."""
+def _sum_over_ranks(t: torch.Tensor, group, inplace: bool = False) -> torch.Tensor:
+    """Sum of `t` over the ranks of `group`: a new tensor, or `t` itself overwritten when `inplace`."""
     if _collective == "allgather":
         world = dist.get_world_size(group)
         buf = t.new_empty((world,) + tuple(t.shape))
         dist.all_gather(list(buf.unbind(0)), t.contiguous(), group=group)      # views of one buffer, rank order
-        return buf.sum(dim=0)
-    out = t.clone()
+        return torch.sum(buf, dim=0, out=t) if inplace else buf.sum(dim=0)
+    out = t if inplace else t.clone()
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
     return out
 
@@ -118,15 +118,14 @@ def all_reduce_grads(params: Iterable[torch.Tensor], group=None) -> None:
     if not params:
         return
     grads = [p.grad for p in params]
-    # four launches + one collective, whatever the number of leaves: cat, widen, all-reduce, narrow, scatter back
-    flat = _sum_over_ranks(torch.cat([g.reshape(-1) for g in grads]).to(torch.float64), group).to(grads[0].dtype)
+    # three launches + one collective, whatever the number of leaves: widen into one fp64 buffer (a single multi-tensor
+    # copy), sum over the ranks in place, narrow back into the .grad tensors (a single multi-tensor copy)
+    flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float64, device=grads[0].device)
     views, off = [], 0
     for g in grads:
         n = g.numel()
         views.append(flat[off:off + n].view(g.shape))
         off += n
-    if all(g.dtype == grads[0].dtype for g in grads):
-        torch._foreach_copy_(grads, views)
-    else:
-        for g, v in zip(grads, views):
-            g.copy_(v)
+    torch._foreach_copy_(views, grads)
+    _sum_over_ranks(flat, group, inplace=True)
+    torch._foreach_copy_(grads, views)
