@@ -256,7 +256,15 @@ def roofline_of(job, kern_ms, mode):
     b_fwd, b_bwd = 18.0 + 8.0 / fw, (17.0 if inv else 0.0) + 8.0 / fw
     f_fwd, f_ck, f_inv = flops_per_ray(meta["S"], meta["n_asph"])
     f_bwd = f_inv if inv else f_ck
-    bwd_name = ("trace_bwd_inv_kernel<asph>" if meta["n_asph"] else "trace_bwd_inv_kernel") if inv else "trace_bwd_kernel"
+    # the walk-back kernel launch_bwd_inv picks (csrc/tl_kernels.inc: kInvUnrollMin / kInvUnrollMax)
+    if not inv:
+        bwd_name = "trace_bwd_kernel"
+    elif meta["n_asph"]:
+        bwd_name = "trace_bwd_inv_kernel<true>"
+    elif 3 <= meta["S"] <= 12 and os.environ.get("TL_INV_ROLLED") != "1":
+        bwd_name = f"trace_bwd_inv_unrolled_kernel<{meta['S']}>"
+    else:
+        bwd_name = "trace_bwd_inv_kernel<false>"
     kernels = {}
     for key, bpr, fpr in (("fwd", b_fwd, f_fwd), ("bwd", b_bwd, f_bwd)):
         ms = kern_ms.get(key)
