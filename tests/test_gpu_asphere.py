@@ -85,8 +85,11 @@ def test_asphere_forward_matches_oracle(ta, case):
     w32 = orc.trace_skew_general(*ins, mask, kap, pol, kind, ieee_sqrt=True)       # the oracle's own fp32 run
     got = ta.trace_skew(*[a.to(DEV) for a in ins], mask.to(DEV), kappa=kap.to(DEV), poly=pol.to(DEV))
     ok_g, ok_w = got[4].cpu(), want[4]
-    differ = (ok_g != ok_w).float().mean().item()
-    assert differ <= 2e-3, f"ok masks differ on {differ:.2%} of rays"     # rays within rounding of a failure threshold
+    # masks: equal to the fp64 oracle's except where the oracle's own fp32 run already disagrees with it (rays within
+    # rounding of a failure threshold), + 2 rays of slack; measured on the MI355X: 0 differing rays in both fixtures
+    differ = (ok_g != ok_w).sum().item()
+    assert differ <= 2 + (w32[4] != ok_w).sum().item(), f"ok masks differ on {differ} of {ok_w.numel()} rays"
+    assert (got[5].cpu() != w32[5]).sum().item() <= 2 + (w32[5] != want[5]).sum().item()      # backward-ray flags likewise
     both = ok_g & ok_w & w32[4]
     for i, tol in ((0, 2e-5), (1, 2e-5), (2, 2e-6), (3, 2e-6)):
         d = (got[i].cpu().double() - want[i])[both].abs().max().item()

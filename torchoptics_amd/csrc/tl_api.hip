@@ -32,16 +32,24 @@ int env_int(const char *name, int dflt)
 }
 
 // Launch plan: gridDim.x blocks of kBlock threads per (f, w), each thread tracing R rays.
-// Aim for `target` blocks in total (>> 256 CUs, several per CU) and R rays per thread so
-// the per-block reduction epilogue is amortised.
+// Every block pays a fixed prologue + reduction epilogue worth ~0.3-1 ray of work, so rays per lane want to be
+// several; on the other hand the VALU-bound trace kernels need >= ~4 waves per SIMD in flight (>= ~1024 blocks, see
+// DESIGN.md "What bounds the trace kernels") and an even share per block.  Measured on cfg2, cfg3 at 2^20 / 2^22 / 2^24
+// points and a small cfg5 (profiles/r02_ab_launch_plan.txt): aim for ~`few` blocks until a lane has `rwant` rays, then
+// grow the grid up to `cap` blocks, then let R grow.  Small workloads gain 10-20 % per kernel over a fixed 8192-block
+// target (which gave them R = 1..2 with an uneven share).
 struct Plan { int nbx, R; };
 
-Plan make_plan(int P, int FW, int target, int rmax)
+Plan make_plan(int P, int FW, int cap, int rmax, int few = 2048, int rwant = 8)
 {
-    // nbx blocks per (f, w), about `target` in total; each block takes an equal share (to within one) of the
-    // kBlock-point chunks of the pupil (TL_BLOCK_CHUNKS in tl_kernels.inc); R = the largest share
+    // each block takes an equal share (to within one) of the kBlock-point chunks of the pupil (TL_BLOCK_CHUNKS in
+    // tl_kernels.inc); R = the largest share
     const int64_t chunks = ((int64_t)P + kBlock - 1) / kBlock;
-    int64_t nbx = (target + FW - 1) / FW;
+    int64_t r = chunks * FW / few;                            // rays per lane at ~`few` blocks
+    if (r < 1) r = 1;
+    if (r > rwant) r = rwant;
+    int64_t nbx = (chunks + r - 1) / r;
+    if (nbx * FW > cap) nbx = (cap + FW - 1) / FW;
     if (nbx > chunks) nbx = chunks;
     if (nbx * rmax < chunks) nbx = (chunks + rmax - 1) / rmax;
     if (nbx < 1) nbx = 1;
@@ -53,16 +61,16 @@ Plan make_plan(int P, int FW, int target, int rmax)
 
 Plan plan_fwd(const tl_problem *p)
 {
-    static const int target = env_int("TL_FWD_BLOCKS", 8192), rmax = env_int("TL_FWD_RMAX", 32);
-    return make_plan(p->P, p->F * p->W, target, rmax);
+    static const int cap = env_int("TL_FWD_BLOCKS", 8192), rmax = env_int("TL_FWD_RMAX", 32);
+    static const int few = env_int("TL_PLAN_FEW", 2048), rwant = env_int("TL_PLAN_R", 8);
+    return make_plan(p->P, p->F * p->W, cap, rmax, few, rwant);
 }
 
 Plan plan_bwd(const tl_problem *p)
 {
-    // 8192 blocks = 4.6 rounds of the 1792 resident blocks (7 waves per SIMD): the partially filled last round
-    // weighs less than at 4096 (-2 % on the walk-back kernel, sweep in tools/ab_kernels.py with TL_BWD_BLOCKS)
-    static const int target = env_int("TL_BWD_BLOCKS", 8192), rmax = env_int("TL_BWD_RMAX", 64);
-    return make_plan(p->P, p->F * p->W, target, rmax);
+    static const int cap = env_int("TL_BWD_BLOCKS", 8192), rmax = env_int("TL_BWD_RMAX", 64);
+    static const int few = env_int("TL_PLAN_FEW", 2048), rwant = env_int("TL_PLAN_R", 8);
+    return make_plan(p->P, p->F * p->W, cap, rmax, few, rwant);
 }
 
 int check_problem(const tl_problem *p)
