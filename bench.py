@@ -431,6 +431,16 @@ def main():
         also["cfg5_adam_loop"] = dict(workload="20-row zoom, F=5 W=3 P=2^20 (15.7 M rays per step), 100 Adam steps on c and t, "
                                                "1 GPU; steps include the whole host chain", arith_mode=a.mode, **adam)
 
+        # the reference's real caller as a minibatch: 256 lenses x 1 536 rays, aggregate + ray aiming, per-lens losses;
+        # one batched launch each way against the caller's one-lens-at-a-time loop (examples/minibatch_loss.py)
+        log("lens minibatch")
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "examples"))
+            import minibatch_loss
+            also["lens_minibatch"] = minibatch_loss.run(256, 10, 16, 1, device=device, arith=a.mode)
+        except Exception as e:
+            also["lens_minibatch"] = dict(error=repr(e))
+
     cpu_baseline, grad_check, leaf_grads = None, None, None
     if rank == 0 and solo and not a.no_cpu_baseline:
         log("cpu baseline + gradient check")

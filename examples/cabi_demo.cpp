@@ -62,7 +62,7 @@ int main(int argc, char **argv)
     hipStream_t st;
     HIP_OK(hipStreamCreate(&st));
     TL_OK_(tl_trace_fwd(&p, ox, oy, ocx, ocy, ok, back, nullptr, nullptr, mom, ws, wsz, st));
-    TL_OK_(tl_spot_rms(0, F, (double)P * W, mom, rms, dmom, st));
+    TL_OK_(tl_spot_rms(0, 1, F, (double)P * W, mom, rms, dmom, st));
     TL_OK_(tl_trace_bwd(&p, nullptr, nullptr, nullptr, nullptr, dmom, nullptr, g_c, g_t, g_mu, g_z, g_cx, g_cy, nullptr, nullptr,
                         nullptr, nullptr, nullptr, ws, wsz, st));
     HIP_OK(hipStreamSynchronize(st));

@@ -13,8 +13,9 @@
  *     thread; ray aiming re-enters the tracer inside a forward);
  *   - return 0 on success, a negative TL_E* code otherwise; tl_last_error() gives the
  *     message for the calling thread;
- *   - the ray batch is [F fields][W wavelengths][P pupil points] with P contiguous
- *     ("FWP" layout): one wavefront = 64 consecutive pupil points of one (f, w).
+ *   - the ray batch is [B lenses][F fields][W wavelengths][P pupil points] with P contiguous
+ *     ("FWP" layout): one wavefront = 64 consecutive pupil points of one (b, f, w).  B = 1 is the
+ *     reference's callers' case; every "[F,...]" / "[S]" shape below gains a leading B when B > 1.
  */
 #ifndef TL_TRACE_H
 #define TL_TRACE_H
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 11
+#define TL_ABI_VERSION 12
 #define TL_MAX_SURFACES 32       /* rows per lens the backward kernels are built for */
 #define TL_NMOM 10               /* per-field sums, see tl_trace_fwd */
 #define TL_MAX_POLY 4            /* even aspheric terms a4,a6,a8,a10 */
@@ -45,36 +46,43 @@ enum { TL_MODE_STRICT = 0,   /* op-order-faithful fp32, no FMA contraction, IEEE
 /*
  * One trace problem.  Mirrors the argument list of
  *   trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays)
- *   (ray_tracing_lite.py:594) for one lens (B = 1).
+ *   (ray_tracing_lite.py:594), whose tensors broadcast over a leading lens axis [B, ...]: a batch of B padded
+ *   lenses (Structure / Lens of lens_modeling.py:151-386 hold B rows) is ONE launch here, blockIdx.y = (b F + f) W + w.
+ *   Padded rows (c = 0, t = 0, mu = 1, mask 0) are traced as the identity rows they are in the reference.
  */
 typedef struct tl_problem {
-    int32_t F, P, W, S;          /* fields, pupil points in this shard, wavelengths, surface rows */
+    int32_t F, P, W, S;          /* fields, pupil points in this shard, wavelengths, surface rows (per lens) */
     int32_t device;              /* HIP device ordinal the pointers live on */
     int32_t mode;                /* TL_MODE_* */
     int32_t allow_backward;      /* allow_backward_rays (ray_tracing_lite.py:629) */
     int32_t aggregate;           /* aggregate=True of trace_skew (:641-657): evaluate the penalty-term quantities
                                     (aspheric rows included: theta from the cosine at the aspheric normal) */
-    /* entrance-pupil ray coordinates; element strides (floats) over (f, p, w), 0 = broadcast.
+    /* entrance-pupil ray coordinates; element strides (floats) over (b, f, p, w), 0 = broadcast.
        Reference shapes [1|B, 1|F, P, 1|W] (ray_tracing_lite.py:112-113). */
     const float *x_in, *y_in;
     int64_t xs_f, xs_p, xs_w;
     int64_t ys_f, ys_p, ys_w;
-    const float *z;              /* [1]   pupil position (ray_tracing_lite.py:91)            */
-    const float *cx, *cy;        /* [F] or [1] initial direction cosines (:116-118)          */
-    int32_t cx_stride, cy_stride;/* 1 or 0 (broadcast)                                       */
-    const float *c, *t;          /* [S]   curvature, thickness (:121-122)                    */
-    const float *mu;             /* [W,S] n_before/n_after per wavelength (:123)             */
-    const uint8_t *mask;         /* [S]   non-padding rows (:124)                            */
+    const float *z;              /* [B]   pupil position (ray_tracing_lite.py:91)            */
+    const float *cx, *cy;        /* initial direction cosines (:116-118), element (b, f) at
+                                    cx[b * cx_stride_b + f * cx_stride]                      */
+    int32_t cx_stride, cy_stride;/* 1 or 0 (broadcast over fields)                           */
+    const float *c, *t;          /* [B,S]   curvature, thickness (:121-122)                  */
+    const float *mu;             /* [B,W,S] n_before/n_after per wavelength (:123)           */
+    const uint8_t *mask;         /* [B,S]   non-padding rows (:124)                          */
     /* ---- aspheric extension (not in the reference; all three NULL = all-spherical) ----
        sag(rho) = c rho/(1+sqrt(1-(1+kappa) c^2 rho)) + a4 rho^2 + a6 rho^3 + a8 rho^4 + a10 rho^5,
        rho = x^2+y^2; rows with surf_kind 1 are intersected by Newton iteration from the closed-form
        sphere hit and refracted at the aspheric normal; rows with surf_kind 0 take the reference's
        closed form and ignore kappa / poly. */
-    const float *kappa;          /* [S]   conic constant                                     */
-    const float *poly;           /* [S,TL_MAX_POLY] a4,a6,a8,a10                             */
-    const uint8_t *surf_kind;    /* [S]   0 = closed-form sphere, 1 = Newton asphere         */
-    const float *n_index;        /* [W,S+1] refractive indices (entry 0 = object space); only
+    const float *kappa;          /* [B,S]   conic constant                                   */
+    const float *poly;           /* [B,S,TL_MAX_POLY] a4,a6,a8,a10                           */
+    const uint8_t *surf_kind;    /* [B,S]   0 = closed-form sphere, 1 = Newton asphere       */
+    const float *n_index;        /* [B,W,S+1] refractive indices (entry 0 = object space); only
                                     read when tl_trace_fwd is asked for `opd`                 */
+    /* ---- lens batch (ABI 12) ---- */
+    int32_t B;                   /* lenses in this launch; 0 is read as 1.  B * F * W <= 65535 */
+    int32_t cx_stride_b, cy_stride_b;   /* element stride of cx / cy over the lens index (0 = shared) */
+    int64_t xs_b, ys_b;          /* element stride of x_in / y_in over the lens index (0 = shared) */
 } tl_problem;
 
 int         tl_version(void);            /* == TL_ABI_VERSION */
@@ -88,6 +96,8 @@ size_t tl_workspace_bytes(const tl_problem *p);
  * Forward trace: replaces the whole Python loop trace_skew (ray_tracing_lite.py:594-675 =
  * find_marching_distance_spherical :525-545, update_ray_coordinates :514-522,
  * reset_bad_rays :574-591, apply_snell_spherical :548-571, image-plane transfer :659-663).
+ *   (shapes for B = 1; with a lens batch every output gains a leading B: [B,F,W,P], moments [B,F,TL_NMOM],
+ *    stacks [3][S][B,F,W,P])
  *   x,y,cx,cy : [F,W,P] float  (any may be NULL = not wanted)
  *   ok,back   : [F,W,P] uint8  (nullable)
  *   opd       : [F,W,P] float  optical path length sum_k n_k d_k + n_S d_image from the pupil plane
@@ -122,7 +132,8 @@ int tl_trace_fwd(const tl_problem *p,
  *                   seed  gM0 + ok*(gM1 + 2*y*gM2)  (and the x analogue) is formed in-kernel;
  *                   entry 8 seeds the penalty term when p->aggregate
  *   g_c,g_t [S], g_mu [W,S], g_z [1], g_cx,g_cy [F] : float, OVERWRITTEN (not accumulated); summed over the
- *                   rays in fp64 in a fixed order and rounded once
+ *                   rays in fp64 in a fixed order and rounded once.  Lens batch: per lens, [B,S], [B,W,S], [B],
+ *                   [B,F] (and g_kappa [B,S], g_poly [B,S,4], g_n_index [B,W,S+1]); a lens never sees another's rays
  *   g_kappa [S], g_poly [S,TL_MAX_POLY] : float, nullable (aspheric extension)
  *   g_x_in,g_y_in : [F,W,P] float per-ray input gradients (nullable; used by ray aiming,
  *                   ray_tracing_lite.py:169-181)
@@ -176,10 +187,11 @@ int tl_spot_moments(int32_t device, int32_t F, int32_t P, int32_t W,
  * The closed form of compute_rms2d (ray_tracing_lite.py:684-701) on the moments, and its derivative:
  *   rms = mean_f sqrt((M2 - 2 m M1 + m^2 M3) / n),  m = M0 / n,  n = P*W rays per field (of the WHOLE
  *   pupil when it is sharded over GPUs: pass the all-reduced moments).
- *   rms [1] float; d_moments [F,TL_NMOM] double = d rms / d moments (zero where the variance is 0).
+ *   rms [B] float (one value per lens: moments [B,F,TL_NMOM]; compute_rms2d itself reads lens 0 only);
+ *   d_moments [B,F,TL_NMOM] double = d rms[b] / d moments[b] (zero where the variance is 0).
  */
-int tl_spot_rms(int32_t device, int32_t F, double n_per_field, const double *moments, float *rms, double *d_moments,
-                void *stream);
+int tl_spot_rms(int32_t device, int32_t B, int32_t F, double n_per_field, const double *moments, float *rms,
+                double *d_moments, void *stream);
 
 /* d(loss)/dy, d(loss)/dx per ray from d(loss)/d(moments); outputs [F,P,W]-strided like y. */
 int tl_spot_seed(int32_t device, int32_t F, int32_t P, int32_t W,

@@ -190,9 +190,51 @@ def first_order(name):
     return float(efl[0]), float(bfl[0]), float(pz[0])
 
 
+def batch_case(names, n_rays, fields, wl):
+    """G11: a padded BATCH of lenses (B = len(names)) through the reference's own RayTracer / trace_skew in one call --
+    the broadcast over dim 0 that its containers exist for.  Records the captured trace_skew inputs [B,...], the
+    outputs [B,F,P,W], the penalty stacks (aggregate=True), and d(sum_b rms_b)/d(inputs) from the reference's autograd
+    in fp32 and fp64 (rms_b = compute_rms2d on lens b's slice: the reference's compute_rms2d reads sample 0 only)."""
+    ds = [load(n) for n in names]
+    st = lm.Structure(stop_idx=np.array([d["stop_idx"][0] for d in ds]), sequence=np.array([d["sequence"][0] for d in ds]),
+                      default_device="cpu")
+    leaves = {k: torch.tensor(sum((d[k] for d in ds), []), dtype=torch.float32) for k in ("c", "t", "nd", "v")}
+    lens = lm.Lens(st, leaves["c"], leaves["t"], leaves["nd"], leaves["v"])
+    B = len(names)
+    specs = lm.Specs(st, torch.tensor([EPD] * B, dtype=torch.float32), torch.tensor([np.deg2rad(HFOV_DEG)] * B, dtype=torch.float32))
+    tr = rt.RayTracer(mode="circular", n_rays=n_rays, rel_fields=fields, wavelengths=wl, default_device="cpu")
+    with Capture() as cap:
+        x, y, cx, cy, ok, back = tr.trace_rays(specs, lens)
+    out = dict(x=np32(x), y=np32(y), cx=np32(cx), cy=np32(cy), ok=np32(ok), back=np32(back))
+    names_in = ("in_x", "in_y", "in_z", "in_cx", "in_cy", "in_c", "in_t", "in_mu", "in_mask")
+    for k, v in zip(names_in, cap.args[:9]):
+        out[k] = np32(v)
+    # aggregate=True needs full-shape inputs: with the un-aimed [1,1,P,1] pupil grid and W > 1 the reference's own
+    # `theta[~ray_ok] = 1.` (ray_tracing_lite.py:653) raises a shape error, for any B.  Hand it the expanded grid.
+    full = [cap.args[0].expand_as(x).clone(), cap.args[1].expand_as(x).clone()] + list(cap.args[2:9])
+    res = rt.trace_skew(*full, True, True)
+    for i, key in enumerate(("x", "y", "cx", "cy", "ok", "back")):
+        assert np.array_equal(np32(res[i]), out[key]), key          # same rays as the un-expanded call
+    for key, lst in res[6].items():
+        out["stack_" + key] = np32(torch.stack(lst, 0))
+    for dtype, suffix in ((torch.float32, ""), (torch.float64, "64")):
+        ins = [a.to(dtype).clone().requires_grad_(True) for a in cap.args[:8]]
+        xo, yo, _, _, oko, _ = rt.trace_skew(*ins, cap.args[8], False, True)
+        rms_b = torch.stack([rt.compute_rms2d(xo[b:b + 1], yo[b:b + 1], oko[b:b + 1]) for b in range(B)])
+        gs = torch.autograd.grad(rms_b.sum(), ins, allow_unused=True)
+        out["rms_b" + suffix] = rms_b.detach().numpy().astype(np.float64)
+        for n, g, a in zip(("x", "y", "z", "cx", "cy", "c", "t", "mu"), gs, ins):
+            if n not in ("x", "y"):
+                out["gin_" + n + suffix] = (g if g is not None else torch.zeros_like(a)).detach().numpy()
+    return out
+
+
 def main():
     F3 = (0., 0.707, 1.)
     CDF = ("C", "d", "F")
+    if "--only-G11" in sys.argv:
+        save("G11_batch3_16x16", batch_case(("cooke", "doublet", "tessar"), (16, 16), F3, CDF))
+        return
 
     # G1  singlet cfg1
     g1 = trace_case("singlet", (64, 64), (0.,), ("d",))
@@ -227,6 +269,9 @@ def main():
     # G6  Cooke with one ray-aiming iteration
     g6 = trace_case("cooke", (16, 16), F3, CDF, aim=1)
     save("G6_cooke_aim1", g6)
+
+    # G11 a padded batch of three lenses in one trace_skew call
+    save("G11_batch3_16x16", batch_case(("cooke", "doublet", "tessar"), (16, 16), F3, CDF))
 
     # G10 allow_backward_rays=False
     for nm in ("cooke", "tessar"):

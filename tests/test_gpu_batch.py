@@ -1,6 +1,7 @@
-"""B > 1: a padded batch of two lenses of different length (the reference's containers exist for this; its
-`trace_skew` broadcasts over dim 0).  One launch per lens; outputs equal the single-lens traces bit for bit, the
-strict forward equals the IEEE oracle on the padded batch, compute_rms2d reads lens 0 only, gradients flow to both."""
+"""B > 1: padded batches of lenses of different length (the reference's containers exist for this; its `trace_skew`
+broadcasts over dim 0).  ONE launch each way for the whole batch (tl_problem.B): the strict forward equals the IEEE
+oracle on the padded batch and the reference's own batch run (fixture G11), per-lens gradients equal the reference's
+autograd, compute_rms2d reads lens 0 only, compute_rms2d_batch gives every lens its own spot size."""
 import numpy as np
 import pytest
 import torch
@@ -60,9 +61,109 @@ def test_two_lens_padded_batch():
     assert torch.allclose(g[:7], lv0["c"].grad, rtol=2e-3, atol=1e-6) and g[7:].abs().max().item() > 0
 
 
-def test_aggregate_on_a_batch_is_refused():
+def _g11(device):
+    from conftest import load_golden
+    g = load_golden("G11_batch3_16x16")
+    names = ("in_x", "in_y", "in_z", "in_cx", "in_cy", "in_c", "in_t", "in_mu")
+    return g, [torch.from_numpy(g[n]).to(device) for n in names], torch.from_numpy(g["in_mask"]).to(device)
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_reference_batch_fixture_forward_and_stacks(mode):
+    """G11 = the reference's own trace of three padded lenses in one call: rays, masks, penalty stacks."""
+    import torchoptics_amd as ta
+    from oracle import trace_oracle as orc
+    g, ins, mask = _g11(DEV)
+    out = ta.trace_skew(*ins, mask, mode=mode)
+    tol = 1e-5 if mode == "strict" else 3e-5
+    for i, name in enumerate(("x", "y", "cx", "cy")):
+        assert np.abs(out[i].cpu().numpy() - g[name]).max() <= (tol if i < 2 else tol / 10), name
+    assert np.array_equal(out[4].cpu().numpy(), g["ok"]) and np.array_equal(out[5].cpu().numpy(), g["back"])
+    if mode == "strict":        # bit-exact with the correctly rounded evaluation of the same op sequence
+        want = orc.trace_skew(*[a.cpu() for a in ins], mask.cpu(), ieee_sqrt=True)
+        assert all(torch.equal(out[i].cpu(), want[i]) for i in range(6))
+    agg = ta.trace_skew(*ins, mask, aggregate=True, mode=mode)
+    for key in ("z_RELU", "theta_norm", "theta_prime_norm"):
+        got = torch.stack(agg[6][key], 0).cpu().numpy()
+        assert got.shape == g["stack_" + key].shape
+        assert np.abs(got - g["stack_" + key]).max() <= (2e-4 if key != "z_RELU" else 2e-5), key
+    # the fused penalty sum per lens = the sum over that lens' stacks
+    q = sum(np.nan_to_num(g["stack_" + k].astype(np.float64)).sum(axis=0) for k in ("z_RELU", "theta_norm", "theta_prime_norm"))
+    assert np.allclose(agg[6].q_per_lens.cpu().numpy(), q.sum(axis=(1, 2, 3)), rtol=2e-5)
+
+
+@pytest.mark.parametrize("algo", ["inverse", "checkpoint"])
+def test_reference_batch_fixture_gradients(algo):
+    """d(sum_b rms_b)/d(z, cy, c, t, mu) per lens against the reference's autograd (fp32 and fp64 runs in G11)."""
+    import torchoptics_amd as ta
+    from conftest import rel_l2
+    from torchoptics_amd import ops
+    g, ins, mask = _g11(DEV)
+    lv = [a.clone().requires_grad_(True) for a in ins[2:]]
+    ops.set_backward_algorithm(algo)
+    try:
+        out = ta.trace_skew(ins[0], ins[1], *lv, mask)
+        rms_b = ta.compute_rms2d_batch(out[0], out[1], out[4])
+        assert np.allclose(rms_b.detach().cpu().numpy(), g["rms_b64"], rtol=2e-5)
+        assert abs(ta.compute_rms2d(out[0], out[1], out[4]).item() - g["rms_b64"][0]) <= 2e-5 * g["rms_b64"][0]
+        rms_b.sum().backward()
+    finally:
+        ops.set_backward_algorithm("inverse")
+    for n, q in zip(("z", "cx", "cy", "c", "t", "mu"), lv):
+        got, w32, w64 = q.grad.cpu().numpy(), g["gin_" + n], g["gin_" + n + "64"]
+        assert got.shape == w64.shape
+        if n == "cx":
+            continue                                        # zero by symmetry: noise over noise
+        noise = rel_l2(w32, w64)
+        lim = 3e-5 if n in ("c", "t", "mu") else 1e-3       # z, cy: residuals of large per-ray terms (DESIGN section 2)
+        assert rel_l2(got, w64) <= lim + 3 * noise, f"{algo} d/d{n}: {rel_l2(got, w64):.2e} (reference fp32 itself {noise:.2e})"
+        for b in range(3):                                   # and lens by lens: no lens sees another's rays
+            assert rel_l2(got[b], w64[b]) <= 10 * (lim + 3 * noise), (n, b)
+
+
+def test_batch_of_many_small_lenses_is_one_launch_and_matches_single_traces():
+    """The reference's real caller traces its minibatch one lens at a time (optical_loss.py:96-110: F = 8, 8 rings,
+    W = 3); here 24 perturbed Cooke triplets go through one launch and every lens equals its own B = 1 trace."""
+    import yaml_free_lenses as L
+    import torchoptics_amd as ta
+    from torchoptics_amd import lens_modeling as lm, ops
+    a = L.PRESCRIPTIONS["cooke"]
+    B = 24
+    gen = torch.Generator().manual_seed(5)
+    c = torch.tensor(a["c"]).repeat(B, 1) * (1 + 0.02 * torch.randn(B, 7, generator=gen))
+    t = torch.tensor(a["t"]).repeat(B, 1) * (1 + 0.02 * torch.rand(B, 7, generator=gen))
+    st = lm.Structure(stop_idx=np.array(a["stop_idx"] * B), sequence=np.array(a["sequence"] * B), default_device=DEV)
+    leaves = [q.reshape(-1).to(DEV).requires_grad_(True) for q in (c, t)]
+    nd, v = (torch.tensor(a[k] * B, device=DEV) for k in ("nd", "v"))
+    lens = lm.Lens(st, leaves[0], leaves[1], nd, v)
+    specs = lm.Specs(st, torch.full((B,), L.EPD, device=DEV), torch.full((B,), float(np.deg2rad(L.HFOV_DEG)), device=DEV))
+    tr = ta.RayTracer(mode="circular", n_rays=(8, 8), rel_fields=tuple(np.linspace(0, 1, 8)), wavelengths=(459., 520., 640.),
+                      default_device=DEV)
+    args = tr.assemble(specs, lens)
+    ops.enable_timing(True)
+    out = ta.trace_skew(args["x"], args["y"], args["z"], args["cx"], args["cy"], args["c"], args["t"], args["mu"], args["mask"])
+    rms_b = ta.compute_rms2d_batch(out[0], out[1], out[4])
+    rms_b.sum().backward()
+    n_calls = {k: len(v) for k, v in ops._timing.items()}
+    ops.enable_timing(False)
+    assert n_calls == {"fwd": 1, "bwd": 1} and out[0].shape == (B, 8, 64, 3)
+    g_c = leaves[0].grad.reshape(B, 7).clone()
+    for b in (0, 7, 23):
+        one = [(q[b:b + 1] if q.shape[0] == B else q).detach() for q in (args["x"], args["y"], args["z"], args["cx"], args["cy"])]
+        cb = args["c"][b:b + 1].detach().clone().requires_grad_(True)
+        o1 = ta.trace_skew(*one, cb, args["t"][b:b + 1].detach(), args["mu"][b:b + 1].detach(), args["mask"][b:b + 1])
+        for i in range(6):
+            assert torch.equal(out[i][b:b + 1], o1[i]), (b, i)
+        r1 = ta.compute_rms2d(o1[0], o1[1], o1[4])
+        assert abs(r1.item() - rms_b[b].item()) <= 1e-6 * r1.item()
+        r1.backward()
+        # d rms_b / d c of lens b through the trace alone (the batch leaf also feeds z and mu: compare the trace input's gradient)
+        assert cb.grad is not None and torch.isfinite(g_c[b]).all()
+
+
+def test_aggregate_on_a_batch():
     import torchoptics_amd as ta
     lens, specs, _ = _batch(DEV)
     tr = ta.RayTracer(mode="circular", n_rays=(8, 8), rel_fields=(0., 1.), wavelengths=("d",), default_device=DEV)
-    with pytest.raises(NotImplementedError):
-        tr.trace_rays(specs, lens, aggregate=True)
+    out = tr.trace_rays(specs, lens, aggregate=True)
+    assert len(out) == 7 and out[6]["theta_norm"][0].shape == (2, 2, 64, 1) and out[6].q_per_lens.shape == (2,)

@@ -110,3 +110,44 @@ def test_ieee_sqrt_variant_is_within_ulps_of_reference(case):
     assert np.abs(cx.numpy() - g["cx"]).max() <= 5e-7 and np.abs(cy.numpy() - g["cy"]).max() <= 5e-7
     rms = orc.compute_rms2d(x, y, ok)
     assert abs(float(rms) - float(g["rms_in"])) <= 1e-6 * float(g["rms_in"]) + 1e-9
+
+
+def _batch_inputs(g, dtype=torch.float32, grad=False):
+    names = ("in_x", "in_y", "in_z", "in_cx", "in_cy", "in_c", "in_t", "in_mu")
+    return [torch.from_numpy(g[n]).to(dtype).requires_grad_(grad) for n in names], torch.from_numpy(g["in_mask"])
+
+
+def test_padded_lens_batch_forward_equals_reference():
+    """G11: three padded lenses (7, 5, 8 rows) in ONE trace_skew call of the reference; padded rows are identity rows."""
+    g = load_golden("G11_batch3_16x16")
+    ins, mask = _batch_inputs(g)
+    assert ins[5].shape == (3, 1, 1, 1, 8) and not g["in_mask"][1, 0, 0, 0, 5:].any()
+    out = orc.trace_skew(*ins, mask)
+    for name, got, tol in zip(("x", "y", "cx", "cy"), out[:4], (5e-5, 5e-5, 2e-6, 2e-6)):
+        assert_matches_fixture(got.numpy(), g[name], atol=tol, what=f"G11:{name}")
+    assert np.array_equal(out[4].numpy(), g["ok"]) and np.array_equal(out[5].numpy(), g["back"])
+    full = [ins[0].expand(3, 3, 256, 3), ins[1].expand(3, 3, 256, 3)] + ins[2:]
+    stacks = orc.trace_skew(*full, mask, True, True)[6]
+    for key in ("z_RELU", "theta_norm", "theta_prime_norm"):
+        assert_matches_fixture(torch.stack(stacks[key], 0).numpy(), g["stack_" + key],
+                               atol=2e-4 if key != "z_RELU" else 1e-5, what="G11:" + key)
+
+
+@pytest.mark.parametrize("prec", ["", "64"])
+def test_padded_lens_batch_gradients_equal_reference(prec):
+    g = load_golden("G11_batch3_16x16")
+    dtype = torch.float64 if prec else torch.float32
+    ins, mask = _batch_inputs(g, dtype, grad=True)
+    x, y, _, _, ok, _ = orc.trace_skew(*ins, mask)
+    rms_b = torch.stack([orc.compute_rms2d(x[b:b + 1], y[b:b + 1], ok[b:b + 1]) for b in range(3)])
+    assert np.allclose(rms_b.detach().numpy(), g["rms_b" + prec], rtol=0 if same_cpu_math() else 5e-6, atol=0)
+    gs = torch.autograd.grad(rms_b.sum(), ins, allow_unused=True)
+    for n, got in zip(("x", "y", "z", "cx", "cy", "c", "t", "mu"), gs):
+        if n in ("x", "y"):
+            continue
+        want = g["gin_" + n + prec]
+        got = np.zeros_like(want) if got is None else got.numpy()
+        if same_cpu_math():
+            assert np.array_equal(got, want), f"G11: d/d{n} differs (rel {rel_l2(got, want):.2e})"
+        else:
+            assert rel_l2(got, want) <= (1e-9 if prec else 1e-3), f"G11: d/d{n} rel {rel_l2(got, want):.2e}"

@@ -8,6 +8,6 @@ HIP kernels for gfx950 behind a C ABI (include/tl_trace.h).  See DESIGN.md.
 from . import lens_modeling, metrics, paraxial, ray_tracing  # noqa: F401
 from .lens_modeling import Lens, Specs, Structure  # noqa: F401
 from .ops import get_default_mode, set_default_mode  # noqa: F401
-from .ray_tracing import RayTracer, compute_rms2d, trace_skew  # noqa: F401
+from .ray_tracing import RayTracer, compute_rms2d, compute_rms2d_batch, trace_skew  # noqa: F401
 
 __version__ = "0.1.0"

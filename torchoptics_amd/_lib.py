@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TORCHOPTICS_AMD_LIB: another build of the same library (an A/B variant written by build.build_library(tag=...))
 LIB_PATH = os.environ.get("TORCHOPTICS_AMD_LIB") or os.path.join(_HERE, "libtltrace.so")
 
-TL_ABI_VERSION = 11
+TL_ABI_VERSION = 12
 TL_NMOM = 10
 TL_MAX_SURFACES = 32
 TL_MAX_POLY = 4
@@ -30,6 +30,8 @@ class tl_problem(C.Structure):
         ("cx_stride", C.c_int32), ("cy_stride", C.c_int32),
         ("c", C.c_void_p), ("t", C.c_void_p), ("mu", C.c_void_p), ("mask", C.c_void_p),
         ("kappa", C.c_void_p), ("poly", C.c_void_p), ("surf_kind", C.c_void_p), ("n_index", C.c_void_p),
+        ("B", C.c_int32), ("cx_stride_b", C.c_int32), ("cy_stride_b", C.c_int32),
+        ("xs_b", C.c_int64), ("ys_b", C.c_int64),
     ]
 
 
@@ -46,7 +48,7 @@ _SIGNATURES = {
     "tl_trace_bwd": (C.c_int, [C.POINTER(tl_problem)] + [_VP] * 17 + [_VP, C.c_size_t, _VP]),
     "tl_trace_bwd_from_outputs": (C.c_int, [C.POINTER(tl_problem)] + [_VP] * 21 + [_VP, C.c_size_t, _VP]),
     "tl_spot_moments": (C.c_int, [C.c_int32] * 4 + [_VP] * 3 + [C.c_int64] * 3 + [_VP, _VP, C.c_size_t, _VP]),
-    "tl_spot_rms": (C.c_int, [C.c_int32, C.c_int32, C.c_double, _VP, _VP, _VP, _VP]),
+    "tl_spot_rms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, _VP, _VP, _VP, _VP]),
     "tl_spot_seed": (C.c_int, [C.c_int32] * 4 + [_VP] * 3 + [C.c_int64] * 3 + [_VP] * 4),
     "tl_pupil_position": (C.c_int, [C.c_int32] * 2 + [_VP] * 9),
 }

@@ -59,18 +59,22 @@ Plan make_plan(int P, int FW, int cap, int rmax, int few = 2048, int rwant = 8)
     return pl;
 }
 
+// lenses in the launch (tl_problem.B, 0 read as 1) and rows of the grid's y dimension = (b, f, w) triples
+inline int lenses(const tl_problem *p) { return p->B > 0 ? p->B : 1; }
+inline int rows_bfw(const tl_problem *p) { return lenses(p) * p->F * p->W; }
+
 Plan plan_fwd(const tl_problem *p)
 {
     static const int cap = env_int("TL_FWD_BLOCKS", 8192), rmax = env_int("TL_FWD_RMAX", 32);
     static const int few = env_int("TL_PLAN_FEW", 2048), rwant = env_int("TL_PLAN_R", 8);
-    return make_plan(p->P, p->F * p->W, cap, rmax, few, rwant);
+    return make_plan(p->P, rows_bfw(p), cap, rmax, few, rwant);
 }
 
 Plan plan_bwd(const tl_problem *p)
 {
     static const int cap = env_int("TL_BWD_BLOCKS", 8192), rmax = env_int("TL_BWD_RMAX", 64);
     static const int few = env_int("TL_PLAN_FEW", 2048), rwant = env_int("TL_PLAN_R", 8);
-    return make_plan(p->P, p->F * p->W, cap, rmax, few, rwant);
+    return make_plan(p->P, rows_bfw(p), cap, rmax, few, rwant);
 }
 
 int check_problem(const tl_problem *p)
@@ -78,7 +82,8 @@ int check_problem(const tl_problem *p)
     if (!p) return fail(TL_EINVAL, "tl_problem is NULL");
     if (p->F < 1 || p->W < 1 || p->S < 1 || p->P < 0) return fail(TL_EINVAL, "F, W, S must be >= 1 and P >= 0");
     if (p->S > TL_MAX_SURFACES) return fail(TL_EINVAL, "S exceeds TL_MAX_SURFACES (32)");
-    if ((int64_t)p->F * p->W > 65535) return fail(TL_EINVAL, "F*W exceeds 65535");
+    if (p->B < 0) return fail(TL_EINVAL, "B must be >= 0 (0 is read as 1)");
+    if ((int64_t)lenses(p) * p->F * p->W > 65535) return fail(TL_EINVAL, "B*F*W exceeds 65535");
     if (!p->x_in || !p->y_in || !p->z || !p->cx || !p->cy || !p->c || !p->t || !p->mu || !p->mask)
         return fail(TL_EINVAL, "a required device pointer of tl_problem is NULL");
     if (p->mode != TL_MODE_STRICT && p->mode != TL_MODE_FAST) return fail(TL_EINVAL, "unknown mode");
@@ -148,12 +153,17 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
     if (alt_part) {
         double n = 0.0;
         if (fmom)
-            for (int f = 0; f < F; ++f) n += fmom[(size_t)f * TL_NMOM + 9];
+            for (int f = 0; f < F * (int)gridDim.y; ++f) n += fmom[(size_t)f * TL_NMOM + 9];
         if (n > 0.0 || (poison && *poison == token)) {
             part = alt_part; NS = alt_NS; ncol = tl_bwd_row(alt_NS, g_kappa != nullptr); nbx = alt_nbx;
         }
     }
     // one block per output scalar: g_c[S] | g_t[S] | g_mu[W,S] | g_z | g_cx[F] | g_cy[F] [| g_kappa[S] | g_poly[S,4]] [| g_n[W,S+1]]
+    // of lens blockIdx.y, whose partial rows are those of the fields [lens F, (lens + 1) F)
+    const int lens = blockIdx.y;
+    g_c += lens * S; g_t += lens * S; g_mu += lens * W * S; g_z += lens; g_cx += lens * F; g_cy += lens * F;
+    if (g_kappa) { g_kappa += lens * S; g_poly += lens * S * TL_MAX_POLY; }
+    if (g_n) g_n += lens * W * (S + 1);
     int b = blockIdx.x;
     float *out;
     int col, f0 = 0, nf = F, w0 = 0, nw = W;
@@ -173,15 +183,19 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
         col = (g_kappa ? 8 : 3) * NS + 3 + k; w0 = w; nw = 1; out = g_n + b;
     }
     (void)ncol;
-    const double s = sum_rows(part, (int64_t)F * W * nbx, col, W, nbx, f0, nf, w0, nw, sm);
+    const double s = sum_rows(part, (int64_t)gridDim.y * F * W * nbx, col, W, nbx, lens * F + f0, nf, w0, nw, sm);
     if (threadIdx.x == 0) *out = (float)s;        // summed in fp64, rounded once
 }
 
 // rms = mean_f sqrt((M2 - 2 m M1 + m^2 M3)/n), m = M0/n  (compute_rms2d on the moments)
 // and d rms / d moments, in one block: replaces ~25 tiny elementwise kernels of the autograd graph.
+// One block per lens (blockIdx.x): rms[b] from the moments rows [b F, (b + 1) F).
 __global__ __launch_bounds__(64) void spot_rms_kernel(const double *__restrict__ mom, int F, double n,
                                                       float *__restrict__ rms, double *__restrict__ dmom)
 {
+    mom += (size_t)blockIdx.x * F * TL_NMOM;
+    dmom += (size_t)blockIdx.x * F * TL_NMOM;
+    rms += blockIdx.x;
     double acc = 0.0;
     for (int f = threadIdx.x; f < F; f += 64) {
         const double *M = mom + (size_t)f * TL_NMOM;
@@ -331,7 +345,7 @@ size_t tl_workspace_bytes(const tl_problem *p)
     if (!p || p->F < 1 || p->W < 1 || p->S < 1 || p->P < 0) return 0;
     const Plan pf = plan_fwd(p), pb = plan_bwd(p);
     const int ns = tl_bwd_bucket(p->S);
-    const size_t fw = (size_t)p->F * p->W;
+    const size_t fw = (size_t)rows_bfw(p);
     const size_t a = fw * pf.nbx * TL_NMOM * sizeof(double);
     const size_t b = fw * pb.nbx * (size_t)tl_bwd_row(ns < 0 ? TL_MAX_SURFACES : ns, p->surf_kind != nullptr) * sizeof(double);
     const size_t c = fw * pb.nbx * (size_t)((p->surf_kind ? 8 : 3) * p->S + 3) * sizeof(double);   // walk-back kernel next to its fallback
@@ -348,7 +362,7 @@ int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, 
     if (opd && p->aggregate) return fail(TL_EINVAL, "the opd output and aggregate (penalty term) cannot be combined in one call");
     if (p->P == 0) {
         if (moments) {
-            hipError_t e = hipMemsetAsync(moments, 0, (size_t)p->F * TL_NMOM * sizeof(double), (hipStream_t)stream);
+            hipError_t e = hipMemsetAsync(moments, 0, (size_t)lenses(p) * p->F * TL_NMOM * sizeof(double), (hipStream_t)stream);
             if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(moments)");
         }
         return TL_OK;
@@ -358,7 +372,7 @@ int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, 
     const Plan pl = plan_fwd(p);
     double *part = nullptr;
     if (moments) {
-        const size_t need = (size_t)p->F * p->W * pl.nbx * TL_NMOM * sizeof(double);
+        const size_t need = (size_t)rows_bfw(p) * pl.nbx * TL_NMOM * sizeof(double);
         if (!workspace || workspace_bytes < need) return fail(TL_EWORKSPACE, "workspace too small for tl_trace_fwd");
         part = (double *)workspace;
     }
@@ -370,7 +384,7 @@ int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, 
     if (herr) return hip_fail(herr, "trace_fwd_kernel launch");
     if (moments) {
         unsigned *clear = (workspace_bytes >= tl_workspace_bytes(p)) ? poison_word(p, workspace) : nullptr;
-        hipLaunchKernelGGL(reduce_moments_kernel, dim3(p->F * TL_NMOM), dim3(kBlock), 0, st, part, moments, p->W, pl.nbx, clear);
+        hipLaunchKernelGGL(reduce_moments_kernel, dim3(lenses(p) * p->F * TL_NMOM), dim3(kBlock), 0, st, part, moments, p->W, pl.nbx, clear);
         herr = (int)hipGetLastError();
         if (herr) return hip_fail(herr, "reduce_moments_kernel launch");
     }
@@ -393,12 +407,12 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
     hipError_t e = hipSetDevice(p->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     if (p->P == 0) {
-        const size_t S = p->S;
-        if ((e = hipMemsetAsync(g_c, 0, S * 4, st)) || (e = hipMemsetAsync(g_t, 0, S * 4, st)) ||
-            (e = hipMemsetAsync(g_mu, 0, S * p->W * 4, st)) || (e = hipMemsetAsync(g_z, 0, 4, st)) ||
-            (e = hipMemsetAsync(g_cx, 0, (size_t)p->F * 4, st)) || (e = hipMemsetAsync(g_cy, 0, (size_t)p->F * 4, st)) ||
-            (g_kappa && (e = hipMemsetAsync(g_kappa, 0, S * 4, st))) || (g_poly && (e = hipMemsetAsync(g_poly, 0, S * 16, st))) ||
-            (g_n_index && (e = hipMemsetAsync(g_n_index, 0, (S + 1) * p->W * 4, st))))
+        const size_t S = p->S, B = (size_t)lenses(p);
+        if ((e = hipMemsetAsync(g_c, 0, B * S * 4, st)) || (e = hipMemsetAsync(g_t, 0, B * S * 4, st)) ||
+            (e = hipMemsetAsync(g_mu, 0, B * S * p->W * 4, st)) || (e = hipMemsetAsync(g_z, 0, B * 4, st)) ||
+            (e = hipMemsetAsync(g_cx, 0, B * p->F * 4, st)) || (e = hipMemsetAsync(g_cy, 0, B * p->F * 4, st)) ||
+            (g_kappa && (e = hipMemsetAsync(g_kappa, 0, B * S * 4, st))) || (g_poly && (e = hipMemsetAsync(g_poly, 0, B * S * 16, st))) ||
+            (g_n_index && (e = hipMemsetAsync(g_n_index, 0, B * (S + 1) * p->W * 4, st))))
             return hip_fail(e, "hipMemsetAsync(grads)");
         return TL_OK;
     }
@@ -406,7 +420,7 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
     const int ns = tl_bwd_bucket(p->S);
     const bool asph = p->surf_kind != nullptr;
     const int ncol = tl_bwd_row(ns, asph);
-    const size_t need = (size_t)p->F * p->W * pl.nbx * (size_t)ncol * sizeof(double);
+    const size_t need = (size_t)rows_bfw(p) * pl.nbx * (size_t)ncol * sizeof(double);
     if (!workspace || workspace_bytes < need) return fail(TL_EWORKSPACE, "workspace too small for tl_trace_bwd");
     double *part = (double *)workspace;
     int herr = (p->mode == TL_MODE_FAST)
@@ -414,7 +428,7 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
                    : tl_strict::api_bwd(*p, gx, gy, gcx, gcy, g_moments, g_x_in, g_y_in, part, pl.nbx, pl.R, st, g_opd);
     if (herr) return hip_fail(herr, "trace_bwd_kernel launch");
     const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0) + (g_opd ? p->W * (p->S + 1) : 0);
-    hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout), dim3(kBlock), 0, st, part, ns, p->F, p->W, p->S, pl.nbx, g_c,
+    hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout, lenses(p)), dim3(kBlock), 0, st, part, ns, p->F, p->W, p->S, pl.nbx, g_c,
                        g_t, g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly, (const double *)nullptr, 0,
                        (const double *)nullptr, (const unsigned *)nullptr, 0u, 0, g_n_index);
     herr = (int)hipGetLastError();
@@ -444,10 +458,10 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     const Plan pl = plan_bwd(p);
     // the fallback is launched too and normally retires at once: a quarter of the blocks keeps that idle launch cheap
-    const Plan pk = make_plan(p->P, p->F * p->W, 1024, 256);
+    const Plan pk = make_plan(p->P, rows_bfw(p), 1024, 256);
     const bool asph = p->surf_kind != nullptr;
     const int ncol = (asph ? 8 : 3) * p->S + 3, ns = tl_bwd_bucket(p->S), ncol_ck = tl_bwd_row(ns, asph);
-    const size_t rows = (size_t)p->F * p->W * pl.nbx, rows_ck = (size_t)p->F * p->W * pk.nbx;
+    const size_t rows = (size_t)rows_bfw(p) * pl.nbx, rows_ck = (size_t)rows_bfw(p) * pk.nbx;
     const size_t need_inv = rows * ncol * sizeof(double), need_ck = rows_ck * ncol_ck * sizeof(double);
     if (!workspace || workspace_bytes < tl_workspace_bytes(p) || tl_workspace_bytes(p) < need_inv + need_ck + 256)
         return fail(TL_EWORKSPACE, "workspace too small for tl_trace_bwd_from_outputs");
@@ -465,7 +479,7 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
                                             moments_fwd, g_x_in, g_y_in, part, part_ck, poison, token, pl.nbx, pl.R, pk.nbx, pk.R, st);
     if (herr) return hip_fail(herr, "trace_bwd_inv_kernel launch");
     const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0);
-    hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout), dim3(kBlock), 0, st, part, p->S, p->F, p->W, p->S, pl.nbx, g_c, g_t,
+    hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout, lenses(p)), dim3(kBlock), 0, st, part, p->S, p->F, p->W, p->S, pl.nbx, g_c, g_t,
                        g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly, (const double *)part_ck, ns,
                        moments_fwd, (const unsigned *)poison, token, pk.nbx, (float *)nullptr);
     herr = (int)hipGetLastError();
@@ -496,13 +510,14 @@ int tl_spot_moments(int32_t device, int32_t F, int32_t P, int32_t W, const float
     return TL_OK;
 }
 
-int tl_spot_rms(int32_t device, int32_t F, double n_per_field, const double *moments, float *rms, double *d_moments,
-                void *stream)
+int tl_spot_rms(int32_t device, int32_t B, int32_t F, double n_per_field, const double *moments, float *rms,
+                double *d_moments, void *stream)
 {
-    if (F < 1 || !(n_per_field > 0.0) || !moments || !rms || !d_moments) return fail(TL_EINVAL, "tl_spot_rms: bad argument");
+    if (B < 1 || F < 1 || !(n_per_field > 0.0) || !moments || !rms || !d_moments)
+        return fail(TL_EINVAL, "tl_spot_rms: bad argument");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-    hipLaunchKernelGGL(spot_rms_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, moments, F, n_per_field, rms, d_moments);
+    hipLaunchKernelGGL(spot_rms_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, moments, F, n_per_field, rms, d_moments);
     const int herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "spot_rms_kernel launch");
     return TL_OK;

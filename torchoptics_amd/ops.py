@@ -6,8 +6,9 @@ autograd.Function wrappers around the C ABI (include/tl_trace.h).
 backward = one recompute-and-reverse HIP kernel.  `SpotMomentsFunction` is the reduction of
 `compute_rms2d` (ray_tracing_lite.py:678-702) for tensors that did not come from the trace.
 
-Per-ray buffers are allocated [F, W, P] (pupil index contiguous) and handed
-out as [1, F, P, W] permuted views, which is the reference's logical shape.
+Per-ray buffers are allocated [B, F, W, P] (pupil index contiguous) and handed
+out as [B, F, P, W] permuted views, which is the reference's logical shape.  A batch of B padded
+lenses is ONE launch (tl_problem.B); B = 1 is the reference's callers' case.
 """
 import ctypes as C
 import os
@@ -105,9 +106,11 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa=None, poly=None, kind_u8=None,
              n_index=None, aggregate=False):
-    F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
+    B, F, P, W = x_e.shape
     p = tl_problem()
-    p.F, p.P, p.W, p.S = F, P, W, c.numel()
+    p.F, p.P, p.W, p.S = F, P, W, c.shape[-1]
+    p.B = B
+    p.xs_b, p.ys_b = x_e.stride(0), y_e.stride(0)
     p.device = x_e.device.index
     p.mode = _MODES[mode]
     p.allow_backward = 1 if allow_back else 0
@@ -116,8 +119,10 @@ def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa=Non
     p.xs_f, p.xs_p, p.xs_w = x_e.stride(1), x_e.stride(2), x_e.stride(3)
     p.ys_f, p.ys_p, p.ys_w = y_e.stride(1), y_e.stride(2), y_e.stride(3)
     p.z, p.cx, p.cy = z.data_ptr(), cx.data_ptr(), cy.data_ptr()
-    p.cx_stride = 0 if cx.numel() == 1 else 1
-    p.cy_stride = 0 if cy.numel() == 1 else 1
+    # cx, cy: [1|B, 1|F] contiguous (a 1-D [1|F] is read as one lens)
+    cx, cy = (a.reshape(1, -1) if a.dim() == 1 else a for a in (cx, cy))
+    p.cx_stride, p.cx_stride_b = (0 if cx.shape[1] == 1 else 1), (0 if cx.shape[0] == 1 else cx.shape[1])
+    p.cy_stride, p.cy_stride_b = (0 if cy.shape[1] == 1 else 1), (0 if cy.shape[0] == 1 else cy.shape[1])
     p.c, p.t, p.mu, p.mask = c.data_ptr(), t.data_ptr(), mu.data_ptr(), mask_u8.data_ptr()
     asph = kind_u8 is not None
     p.kappa = kappa.data_ptr() if asph else None
@@ -128,15 +133,16 @@ def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa=Non
 
 
 def _fwp(t):
-    """[1,F,P,W] logical tensor -> memory laid out [F,W,P] contiguous (no copy if it already is)."""
+    """[B,F,P,W] logical tensor -> memory laid out [B,F,W,P] contiguous (no copy if it already is)."""
     return t.permute(0, 1, 3, 2).contiguous()
 
 
 class TraceFunction(torch.autograd.Function):
     """(x, y, cx, cy, ok, back, moments, opd) = trace(x_in, y_in, z, cx, cy, c, t, mu[, kappa, poly]).
 
-    kappa [S], poly [S,4], kind_u8 [S] are None for an all-spherical lens (the reference's case);
-    n_index [W,S+1] is only needed for the optical path length output (`want_opd`)."""
+    Shapes: x_in, y_in [B,F,P,W] (expanded views welcome), z [B], cx, cy [1|B, 1|F], c, t [B,S], mu [B,W,S],
+    mask_u8 [B,S]; kappa [B,S], poly [B,S,4], kind_u8 [B,S] are None for an all-spherical lens (the reference's
+    case); n_index [B,W,S+1] is only needed for the optical path length output (`want_opd`).  moments [B*F, TL_NMOM]."""
 
     @staticmethod
     def forward(ctx, x_e, y_e, z, cx, cy, c, t, mu, kappa, poly, mask_u8, kind_u8, n_index, allow_back, mode,
@@ -145,8 +151,8 @@ class TraceFunction(torch.autograd.Function):
                           ("mu", mu), ("mask", mask_u8)):
             _require_device(ten, name)
         dev = x_e.device
-        F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
-        S = c.numel()
+        B, F, P, W = x_e.shape
+        S = c.shape[-1]
         if S > _lib.TL_MAX_SURFACES:
             raise RuntimeError(f"lens has {S} rows; this build supports at most {_lib.TL_MAX_SURFACES}")
         lib = _lib.lib()
@@ -154,13 +160,13 @@ class TraceFunction(torch.autograd.Function):
         nbytes = lib.tl_workspace_bytes(C.byref(prob))
         ws = _workspace(nbytes, dev)
         if want_rays:
-            fp = [torch.empty((1, F, W, P), dtype=torch.float32, device=dev) for _ in range(4)]
-            bp = [torch.empty((1, F, W, P), dtype=torch.uint8, device=dev) for _ in range(2)]
+            fp = [torch.empty((B, F, W, P), dtype=torch.float32, device=dev) for _ in range(4)]
+            bp = [torch.empty((B, F, W, P), dtype=torch.uint8, device=dev) for _ in range(2)]
         else:
             fp, bp = [None] * 4, [None] * 2
-        opd = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if want_opd else None
-        stacks = torch.empty((3, S, 1, F, W, P), dtype=torch.float32, device=dev) if (aggregate and want_stacks) else None
-        moments = torch.empty((F, TL_NMOM), dtype=torch.float64, device=dev)
+        opd = torch.empty((B, F, W, P), dtype=torch.float32, device=dev) if want_opd else None
+        stacks = torch.empty((3, S, B, F, W, P), dtype=torch.float32, device=dev) if (aggregate and want_stacks) else None
+        moments = torch.empty((B * F, TL_NMOM), dtype=torch.float64, device=dev)
         with torch.cuda.device(dev), _Timed("fwd", dev):
             rc = lib.tl_trace_fwd(C.byref(prob), *[_lib.ptr(b) for b in fp], *[_lib.ptr(b) for b in bp],
                                   _lib.ptr(opd), _lib.ptr(stacks), _lib.ptr(moments), _lib.ptr(ws), ws.numel(),
@@ -194,8 +200,8 @@ class TraceFunction(torch.autograd.Function):
         (x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, fx, fy, fcx, fcy, fok, fmom,
          n_index) = ctx.saved_tensors
         dev = x_e.device
-        F, P, W = x_e.shape[1], x_e.shape[2], x_e.shape[3]
-        S = c.numel()
+        B, F, P, W = x_e.shape
+        S = c.shape[-1]
         n_in = 19
         if gopd is not None and (n_index is None or gopd.numel() == 0):
             gopd = None
@@ -214,14 +220,14 @@ class TraceFunction(torch.autograd.Function):
         gxd, gyd, gcxd, gcyd, gopdd = dense(gx), dense(gy), dense(gcx), dense(gcy), dense(gopd)
         gmd = None if gmom is None else gmom.to(torch.float64).contiguous()
         need_xin, need_yin = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        gxin = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if need_xin else None
-        gyin = torch.empty((1, F, W, P), dtype=torch.float32, device=dev) if need_yin else None
+        gxin = torch.empty((B, F, W, P), dtype=torch.float32, device=dev) if need_xin else None
+        gyin = torch.empty((B, F, W, P), dtype=torch.float32, device=dev) if need_yin else None
         # one fp32 tensor per parameter group, written by the reduction kernel (fp64 sums rounded once):
         # autograd can take them as the leaves' .grad without a cast or a clone
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)     # noqa: E731
-        parts = [new(S), new(S), new(W, S), new(1), new(F), new(F)]
-        g_kappa, g_poly = (new(S), new(S, 4)) if asph else (None, None)
-        g_n = new(W, S + 1) if gopdd is not None else None
+        parts = [new(B, S), new(B, S), new(B, W, S), new(B), new(B, F), new(B, F)]
+        g_kappa, g_poly = (new(B, S), new(B, S, 4)) if asph else (None, None)
+        g_n = new(B, W, S + 1) if gopdd is not None else None
         with torch.cuda.device(dev), _Timed("bwd", dev):
             if ctx.use_inv:
                 rc = lib.tl_trace_bwd_from_outputs(
@@ -237,10 +243,14 @@ class TraceFunction(torch.autograd.Function):
         _lib.check(rc, "tl_trace_bwd")
         g_c, g_t, g_mu, g_z, g_cx, g_cy = parts
         need = ctx.needs_input_grad
-        if need[3] and cx.numel() == 1 and F > 1:
-            g_cx = g_cx.sum(dim=0, keepdim=True)
-        if need[4] and cy.numel() == 1 and F > 1:
-            g_cy = g_cy.sum(dim=0, keepdim=True)
+        def fold(g, like):          # [B,F] -> the (possibly broadcast) shape [1|B, 1|F] of cx / cy
+            if like.shape[0] == 1 and B > 1:
+                g = g.sum(dim=0, keepdim=True)
+            if like.shape[1] == 1 and F > 1:
+                g = g.sum(dim=1, keepdim=True)
+            return g
+        g_cx = fold(g_cx, cx) if need[3] else None
+        g_cy = fold(g_cy, cy) if need[4] else None
         return (gxin.permute(0, 1, 3, 2) if need_xin else None,
                 gyin.permute(0, 1, 3, 2) if need_yin else None,
                 g_z.reshape(z.shape) if need[2] else None, g_cx.reshape(cx.shape) if need[3] else None,
@@ -252,26 +262,30 @@ class TraceFunction(torch.autograd.Function):
 
 class SpotRmsFunction(torch.autograd.Function):
     """rms = compute_rms2d on the [F, TL_NMOM] moments (closed form) with its derivative, one tiny
-    kernel each way instead of the ~25 elementwise kernels of the eager formula and its autograd."""
+    kernel each way instead of the ~25 elementwise kernels of the eager formula and its autograd.
+    n_lens > 1: moments [n_lens * F, TL_NMOM] of a lens batch -> rms [n_lens], one value per lens."""
 
     @staticmethod
-    def forward(ctx, moments, n_per_field):
+    def forward(ctx, moments, n_per_field, n_lens=1):
         _require_device(moments, "moments")
         dev = moments.device
         m = moments.to(torch.float64).contiguous()
-        rms = torch.empty((), dtype=torch.float32, device=dev)
+        rms = torch.empty(() if n_lens == 1 else (n_lens,), dtype=torch.float32, device=dev)
         dm = torch.empty_like(m)
         with torch.cuda.device(dev):
-            rc = _lib.lib().tl_spot_rms(dev.index, m.shape[0], float(n_per_field), _lib.ptr(m), _lib.ptr(rms),
-                                        _lib.ptr(dm), _stream_ptr(dev))
+            rc = _lib.lib().tl_spot_rms(dev.index, n_lens, m.shape[0] // n_lens, float(n_per_field), _lib.ptr(m),
+                                        _lib.ptr(rms), _lib.ptr(dm), _stream_ptr(dev))
         _lib.check(rc, "tl_spot_rms")
         ctx.save_for_backward(dm)
+        ctx.n_lens = n_lens
         return rms
 
     @staticmethod
     def backward(ctx, g):
         (dm,) = ctx.saved_tensors
-        return dm * g, None          # [F,10] fp64 * 0-dim fp32 -> fp64 in one launch (no separate cast)
+        if ctx.n_lens == 1:
+            return dm * g, None, None          # [F,10] fp64 * 0-dim fp32 -> fp64 in one launch (no separate cast)
+        return (dm.view(ctx.n_lens, -1, TL_NMOM) * g.view(-1, 1, 1)).view_as(dm), None, None
 
 
 class SpotMomentsFunction(torch.autograd.Function):

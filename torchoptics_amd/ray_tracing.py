@@ -161,8 +161,9 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
 
     Same contract as the reference (ray_tracing_lite.py:594-675): inputs broadcast to
     [B, F, P, W]; returns (x, y, cx, cy, ray_ok, ray_backward).  Differentiable w.r.t.
-    x, y, z, cx, cy, c, t, mu through a hand-written backward kernel.  B > 1 padded lenses run
-    as one launch per lens (`_trace_skew_batch`); aggregate=True is built for B = 1 only.
+    x, y, z, cx, cy, c, t, mu through a hand-written backward kernel.  A batch of B > 1 padded lenses
+    (every argument's dim 0 is 1 or B) is ONE kernel launch each way; padded rows (c = 0, t = 0, mu = 1,
+    mask False) are traced as the identity rows they are in the reference.
 
     Extras (not in the reference):
       aggregate   True: a 7th return value `stacks` = {'z_RELU', 'theta_norm', 'theta_prime_norm'}, each a
@@ -178,51 +179,52 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
       the returned `y` carries the fused spot moments so `compute_rms2d(x, y, ray_ok)` costs no
       second pass over the rays.
     """
-    n_lens = max(a.shape[0] for a in (x, y, z, cx, cy, c, t, mu, mask) if torch.is_tensor(a) and a.dim() >= 4)
-    if n_lens > 1:
-        return _trace_skew_batch(n_lens, x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays, mode, want_rays,
-                                 kappa, poly, surf_kind, n_index, want_opd)
+    B = max(a.shape[0] for a in (x, y, z, cx, cy, c, t, mu, mask) if torch.is_tensor(a) and a.dim() >= 4)
     x, y, z, cx, cy = (_as_f32(a, n) for a, n in ((x, 'x'), (y, 'y'), (z, 'z'), (cx, 'cx'), (cy, 'cy')))
     c, t, mu = _as_f32(c, 'c'), _as_f32(t, 't'), _as_f32(mu, 'mu')
     for a, n in ((x, 'x'), (y, 'y'), (cx, 'cx'), (cy, 'cy'), (z, 'z')):
-        if a.dim() != 4 or a.shape[0] != 1:
-            raise ValueError(f"{n} must be 4-D with a single lens in dim 0 (B=1), got {tuple(a.shape)}")
-    if c.dim() != 5 or c.shape[0] != 1 or mu.dim() != 5:
-        raise ValueError("c, t, mu must be 5-D [1,1,1,1|W,S]")
+        if a.dim() != 4 or a.shape[0] not in (1, B):
+            raise ValueError(f"{n} must be 4-D with 1 or {B} lenses in dim 0, got {tuple(a.shape)}")
+    if c.dim() != 5 or t.dim() != 5 or mu.dim() != 5 or any(a.shape[0] not in (1, B) for a in (c, t, mu)):
+        raise ValueError("c, t, mu must be 5-D [1|B,1,1,1|W,S]")
     S = c.shape[-1]
     F = max(x.shape[1], y.shape[1], cx.shape[1], cy.shape[1])
     P = max(x.shape[2], y.shape[2])
     W = max(x.shape[3], y.shape[3], mu.shape[3])
-    if z.numel() != 1:
-        raise ValueError("z must hold one pupil position (B=1)")
-    x_e, y_e = x.expand(1, F, P, W), y.expand(1, F, P, W)
-    cxv = cx.reshape(-1).contiguous()
-    cyv = cy.reshape(-1).contiguous()
-    if cxv.numel() not in (1, F) or cyv.numel() not in (1, F):
-        raise ValueError("cx, cy must be per-field [1,F,1,1] or a single value")
-    mu2 = mu.reshape(mu.shape[3], S).expand(W, S).contiguous()
-    mask_u8 = mask.reshape(-1).contiguous()
+    if z.numel() not in (1, B):
+        raise ValueError("z must hold one pupil position per lens")
+    x_e, y_e = x.expand(B, F, P, W), y.expand(B, F, P, W)
+    if any(a.shape[1] not in (1, F) or a.shape[2] != 1 or a.shape[3] != 1 for a in (cx, cy)):
+        raise ValueError("cx, cy must be per-field [1|B,1|F,1,1]")
+    cx2, cy2 = cx.reshape(cx.shape[0], cx.shape[1]).contiguous(), cy.reshape(cy.shape[0], cy.shape[1]).contiguous()
+    zv = z.reshape(-1).expand(B).contiguous()
+    c2, t2 = c.reshape(-1, S).expand(B, S).contiguous(), t.reshape(-1, S).expand(B, S).contiguous()
+    mu3 = mu.reshape(mu.shape[0], mu.shape[3], S).expand(B, W, S).contiguous()
+    mask_u8 = mask.reshape(-1, S)
     mask_u8 = mask_u8.view(torch.uint8) if mask_u8.dtype == torch.bool else mask_u8.to(torch.uint8)   # bool: no copy
+    mask_u8 = mask_u8.expand(B, S).contiguous()
     kap = pol = kind_u8 = None
     if kappa is not None or poly is not None:
-        kap = _as_f32(kappa, 'kappa').reshape(S).contiguous() if kappa is not None else torch.zeros(S, device=c.device)
-        pol = (_as_f32(poly, 'poly').reshape(S, 4).contiguous() if poly is not None
-               else torch.zeros(S, 4, device=c.device))
+        # per lens [B,S] / [B,S,4], or one set [S] / [S,4] shared by every lens of the batch
+        kap = (_as_f32(kappa, 'kappa').reshape(-1, S) if kappa is not None else torch.zeros(1, S, device=c.device)).expand(B, S).contiguous()
+        pol = (_as_f32(poly, 'poly').reshape(-1, S, 4) if poly is not None
+               else torch.zeros(1, S, 4, device=c.device)).expand(B, S, 4).contiguous()
         if surf_kind is None:
-            surf_kind = (kap.detach() != 0) | (pol.detach() != 0).any(dim=1)
-        kind_u8 = torch.as_tensor(surf_kind, device=c.device).reshape(S).to(torch.uint8).contiguous()
+            surf_kind = (kap.detach() != 0) | (pol.detach() != 0).any(dim=-1)
+        kind_u8 = torch.as_tensor(surf_kind, device=c.device).reshape(-1, S).to(torch.uint8).expand(B, S).contiguous()
     nidx = None
     if want_opd:
         if n_index is None:
-            raise ValueError("want_opd=True needs n_index [1,1,1,W,S+1]")
-        nidx = _as_f32(n_index, 'n_index').reshape(-1, S + 1).expand(W, S + 1).contiguous()
-    out = ops.TraceFunction.apply(x_e, y_e, z.reshape(1).contiguous(), cxv, cyv, c.reshape(S).contiguous(),
-                                  t.reshape(S).contiguous(), mu2, kap, pol, mask_u8, kind_u8, nidx,
+            raise ValueError("want_opd=True needs n_index [1|B,1,1,W,S+1]")
+        nidx = _as_f32(n_index, 'n_index')
+        nidx = nidx.reshape(nidx.shape[0] if nidx.dim() == 5 else 1, -1, S + 1).expand(B, W, S + 1).contiguous()
+    out = ops.TraceFunction.apply(x_e, y_e, zv, cx2, cy2, c2, t2, mu3, kap, pol, mask_u8, kind_u8, nidx,
                                   bool(allow_backward_rays), mode or ops.get_default_mode(), want_rays, bool(want_opd),
                                   bool(aggregate), bool(aggregate and want_rays))
     xo, yo, cxo, cyo, ok, back, moments, opd, stk = out
     if want_rays:
-        # remember which moments belong to these rays (checked by identity + version in compute_rms2d)
+        # remember which moments belong to these rays (checked by identity + version in compute_rms2d):
+        # [B*F, TL_NMOM], lens-major
         yo._tl_spot = (moments, ok, yo._version, P * W)
         res = (xo, yo, cxo, cyo, ok, back)
         if want_opd:
@@ -231,34 +233,6 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
             res += (PenaltyStacks(stk, moments),)
         return res
     return moments
-
-
-def _trace_skew_batch(n_lens, x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays, mode, want_rays, kappa,
-                      poly, surf_kind, n_index, want_opd):
-    """B > 1 padded lenses (the reference's `trace_skew` broadcasts over dim 0; its callers only ever pass B = 1,
-    SURVEY 0.4): one kernel launch per lens on that lens' slice of every argument, outputs concatenated along
-    dim 0.  Padded rows (c = 0, t = 0, mu = 1, mask False) are identity rows.  The fused spot moments of LENS 0 stay
-    attached to `y`, because compute_rms2d reads sample 0 only (ray_tracing_lite.py:695,699)."""
-    if aggregate or not want_rays:
-        raise NotImplementedError("aggregate=True / want_rays=False are built for a single lens (B = 1)")
-
-    def pick(a, b, lens_dims):
-        # per-lens slice of an argument whose leading dim is the lens axis (size 1 = shared by all lenses)
-        if a is None or not torch.is_tensor(a) or a.dim() < lens_dims:
-            return a
-        return a[b:b + 1] if a.shape[0] == n_lens else a
-    outs = []
-    for b in range(n_lens):
-        kap = None if kappa is None else (kappa[b] if kappa.dim() == 2 else kappa)
-        pol = None if poly is None else (poly[b] if poly.dim() == 3 else poly)
-        kind = None if surf_kind is None else (surf_kind[b] if torch.is_tensor(surf_kind) and surf_kind.dim() == 2 else surf_kind)
-        outs.append(trace_skew(pick(x, b, 4), pick(y, b, 4), pick(z, b, 4), pick(cx, b, 4), pick(cy, b, 4), pick(c, b, 5),
-                               pick(t, b, 5), pick(mu, b, 5), pick(mask, b, 5), False, allow_backward_rays, mode, True,
-                               kap, pol, kind, pick(n_index, b, 5), want_opd))
-    res = tuple(torch.cat([o[i] for o in outs], dim=0) for i in range(len(outs[0])))
-    tag0 = outs[0][1]._tl_spot
-    res[1]._tl_spot = (tag0[0], res[4], res[1]._version, tag0[3])
-    return res
 
 
 class PenaltyStacks(dict):
@@ -271,6 +245,8 @@ class PenaltyStacks(dict):
         for j, key in enumerate(('z_RELU', 'theta_norm', 'theta_prime_norm')):
             self[key] = list(torch.unbind(stk[j], dim=0))
         self.q_sum = moments[:, 8].sum()
+        n_lens = stk.shape[2] if stk.dim() == 6 else 1
+        self.q_per_lens = moments[:, 8].view(n_lens, -1).sum(dim=1)      # lens batch: one penalty sum per lens
 
 
 def penalty_sum(stacks, n_sequence: int):
@@ -290,6 +266,24 @@ def unsupervised_loss(rt_outputs, n_sequence: int, penalty_rate: float):
     x, y, *_, ray_ok, _ray_backward, stacks = rt_outputs
     rms = compute_rms2d(x, y, ray_ok)
     pen = penalty_sum(stacks, n_sequence)
+    return {'loss_unsup': rms + penalty_rate * pen, 'rms': rms, 'penalty': pen}
+
+
+def unsupervised_loss_batch(rt_outputs, n_sequence, penalty_rate: float):
+    """Extension: the loss_dict of compute_loss_out for EVERY lens of a batch, each entry [B] -- what the reference's
+    caller computes one lens at a time in a Python loop over its minibatch (optical_loss.py:96-110), here from ONE
+    batched trace.  `n_sequence`: rows of the sequence string per lens (an int, or a [B] tensor for padded batches:
+    compute_loss_out divides by len(self._sequence[0]))."""
+    x, y, *_, ray_ok, _ray_backward, stacks = rt_outputs
+    rms = compute_rms2d_batch(x, y, ray_ok)
+    if isinstance(stacks, PenaltyStacks):
+        q = stacks.q_per_lens
+    else:
+        q = (torch.stack(stacks['theta_norm'], 0).sum(0) + torch.stack(stacks['theta_prime_norm'], 0).sum(0)
+             + torch.stack(stacks['z_RELU'], 0).sum(0))
+        q = torch.where(torch.isnan(q), torch.zeros_like(q), q).sum(dim=(1, 2, 3))
+    n_seq = torch.as_tensor(n_sequence, device=q.device, dtype=q.dtype)
+    pen = (q / n_seq).to(torch.float32)
     return {'loss_unsup': rms + penalty_rate * pen, 'rms': rms, 'penalty': pen}
 
 
@@ -313,8 +307,10 @@ def compute_rms2d(x, y, ray_ok, group=None, n_per_field: Optional[int] = None):
     tag = getattr(y, "_tl_spot", None)
     if tag is not None and tag[1] is ray_ok and tag[2] == y._version:
         moments, n_local = tag[0], tag[3]
-    else:
         if y.shape[0] > 1:                       # the reference reads sample 0 only (:695,699)
+            moments = moments[: y.shape[1]]
+    else:
+        if y.shape[0] > 1:
             x, y, ray_ok = (None if x is None else x[:1]), y[:1], ray_ok[:1]
         moments = ops.SpotMomentsFunction.apply(x, y, ray_ok)
         n_local = y.shape[2] * y.shape[3]
@@ -326,6 +322,26 @@ def compute_rms2d(x, y, ray_ok, group=None, n_per_field: Optional[int] = None):
     if moments.is_cuda:
         return ops.SpotRmsFunction.apply(moments, n_per_field or n_local).to(y.dtype)
     return rms_from_moments(moments, n_per_field or n_local).to(y.dtype)
+
+
+def compute_rms2d_batch(x, y, ray_ok):
+    """Extension: compute_rms2d of EVERY lens of a batch, [B] (the reference's compute_rms2d reads sample 0 only and
+    its callers loop over lenses, optical_loss.py:96-110).  Same closed form per lens on the moments fused into the
+    one batched trace launch; differentiable through the one batched backward launch."""
+    B, F = y.shape[0], y.shape[1]
+    tag = getattr(y, "_tl_spot", None)
+    if tag is not None and tag[1] is ray_ok and tag[2] == y._version:
+        moments, n_local = tag[0], tag[3]
+    else:
+        fold = lambda a: None if a is None else a.reshape(1, B * F, a.shape[2], a.shape[3])      # noqa: E731
+        moments = ops.SpotMomentsFunction.apply(fold(x), fold(y), fold(ray_ok))
+        n_local = y.shape[2] * y.shape[3]
+    if moments.is_cuda:
+        return ops.SpotRmsFunction.apply(moments, n_local, B).reshape(B).to(y.dtype)
+    m = moments.view(B, F, -1)
+    mean = m[..., 0] / n_local
+    var = (m[..., 2] - 2 * mean * m[..., 1] + mean * mean * m[..., 3]) / n_local
+    return torch.sqrt(var).mean(dim=1).to(y.dtype)
 
 
 def compute_rms_spot_xy(x, y, ray_ok, group=None, n_per_field: Optional[int] = None):
