@@ -203,12 +203,13 @@ int tl_spot_seed(int32_t device, int32_t F, int32_t P, int32_t W,
  * Paraxial entrance-pupil position w.r.t. the first vertex -- the `z` argument of the trace
  * (compute_pupil_position, ray_tracing_lite.py:301-350): z = B/A of the ABCD product of the K rows in
  * front of the stop, row k = refraction at curvature c[k] from index n[k] to n[k+1], then a gap t[k].
- *   c, t [K], n [K+1] (n[0] = object space), z [1] (nullable): float.
- *   g_z [1] (nullable): upstream gradient; then g_c, g_t [K] and g_n [K+1] are OVERWRITTEN with
+ *   c, t [B,K], n [B,K+1] (n[.,0] = object space), z [B] (nullable): float; B lenses, one thread each (rows behind a
+ *   lens' own stop padded with c = 0, t = 0, n = 1: identity).
+ *   g_z [B] (nullable): upstream gradient; then g_c, g_t [B,K] and g_n [B,K+1] are OVERWRITTEN with
  *   d(loss)/d(c, t, n).  fp64 inside; one tiny launch instead of the ~25 (+ ~60 in autograd) of the
  *   elementwise / 2x2-matmul chain.
  */
-int tl_pupil_position(int32_t device, int32_t K, const float *c, const float *t, const float *n, float *z,
+int tl_pupil_position(int32_t device, int32_t B, int32_t K, const float *c, const float *t, const float *n, float *z,
                       const float *g_z, float *g_c, float *g_t, float *g_n, void *stream);
 
 #ifdef __cplusplus

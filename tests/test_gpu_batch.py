@@ -40,8 +40,8 @@ def test_two_lens_padded_batch():
                           ieee_sqrt=True)
     for i in range(6):
         assert torch.equal(out[i].cpu(), want[i]), i
-    # (2) each lens of the batch = that lens traced alone (up to the pupil position z: one lens on the GPU takes
-    #     the fp64 tl_pupil_position kernel, a batch the fp32 ABCD chain, so z differs by a rounding)
+    # (2) each lens of the batch = that lens traced alone (tolerances from round 2's first half, when a batch took the
+    #     fp32 ABCD chain for z; now tl_pupil_position serves batches too)
     for b, name in enumerate(("cooke", "doublet")):
         l1, s1, _ = L.build(name, DEV)
         o1 = tr.trace_rays(s1, l1)

@@ -91,7 +91,7 @@ def test_pupil_position_c_abi_edges():
         z = torch.empty(1, device=DEV)
         g = [torch.empty(K, device=DEV), torch.empty(K, device=DEV), torch.empty(K + 1, device=DEV)]
         gz = torch.ones(1, device=DEV)
-        assert lib.tl_pupil_position(0, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), _lib.ptr(z), _lib.ptr(gz),
+        assert lib.tl_pupil_position(0, 1, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), _lib.ptr(z), _lib.ptr(gz),
                                      *[_lib.ptr(q) for q in g], st) == 0
         cd, td, nd = (q.double().cpu().requires_grad_(True) for q in (c, t, n))
         m = torch.eye(2, dtype=torch.float64)
@@ -109,7 +109,35 @@ def test_pupil_position_c_abi_edges():
     z = torch.empty(1, device=DEV)
     bad = [(0, c, c, n, z), (_lib.TL_MAX_SURFACES + 1, c, c, n, z), (4, None, c, n, z), (4, c, c, n, None)]
     for K, a, b, nn, zz_ in bad:
-        rc = lib.tl_pupil_position(0, K, _lib.ptr(a), _lib.ptr(b), _lib.ptr(nn), _lib.ptr(zz_), None, None, None, None, st)
+        rc = lib.tl_pupil_position(0, 1, K, _lib.ptr(a), _lib.ptr(b), _lib.ptr(nn), _lib.ptr(zz_), None, None, None, None, st)
         assert rc != 0 and lib.tl_last_error()
     gz = torch.ones(1, device=DEV)
-    assert lib.tl_pupil_position(0, 4, _lib.ptr(c), _lib.ptr(c), _lib.ptr(n), _lib.ptr(z), _lib.ptr(gz), None, None, None, st) != 0
+    assert lib.tl_pupil_position(0, 1, 4, _lib.ptr(c), _lib.ptr(c), _lib.ptr(n), _lib.ptr(z), _lib.ptr(gz), None, None, None, st) != 0
+    assert lib.tl_pupil_position(0, 0, 4, _lib.ptr(c), _lib.ptr(c), _lib.ptr(n), _lib.ptr(z), None, None, None, None, st) != 0      # B < 1
+
+
+def test_pupil_position_of_a_padded_lens_batch():
+    """B = 3 lenses with different stop rows in one launch (one thread per lens; rows behind a lens' own stop are
+    identity): every lens equals its own single-lens call, values and gradients."""
+    import yaml_free_lenses as L
+    from torchoptics_amd import lens_modeling as lm, paraxial
+    names = ("cooke", "doublet", "tessar")
+    ps = [L.PRESCRIPTIONS[n] for n in names]
+    st = lm.Structure(stop_idx=np.array([p["stop_idx"][0] for p in ps]), sequence=np.array([p["sequence"][0] for p in ps]),
+                      default_device=DEV)
+    flat = {k: torch.tensor(sum((p[k] for p in ps), []), device=DEV) for k in ("c", "t", "nd", "v")}
+    lv = {k: flat[k].clone().requires_grad_(True) for k in ("c", "t", "nd")}
+    z = paraxial.compute_pupil_position(lm.Lens(st, lv["c"], lv["t"], lv["nd"], flat["v"]))
+    assert z.shape == (3,)
+    (z * torch.tensor([1.0, -2.0, 0.5], device=DEV)).sum().backward()
+    o_c = o_g = 0
+    for b, (p, wgt) in enumerate(zip(ps, (1.0, -2.0, 0.5))):
+        st1 = lm.Structure(stop_idx=np.array(p["stop_idx"]), sequence=np.array(p["sequence"]), default_device=DEV)
+        one = {k: torch.tensor(p[k], device=DEV).requires_grad_(k != "v") for k in ("c", "t", "nd", "v")}
+        z1 = paraxial.compute_pupil_position(lm.Lens(st1, one["c"], one["t"], one["nd"], one["v"]))
+        assert torch.equal(z1.reshape(()), z[b].detach().reshape(()))
+        (z1.sum() * wgt).backward()
+        nc, ng = len(p["c"]), len(p["nd"])
+        assert torch.equal(lv["c"].grad[o_c:o_c + nc], one["c"].grad) and torch.equal(lv["t"].grad[o_c:o_c + nc], one["t"].grad)
+        assert torch.equal(lv["nd"].grad[o_g:o_g + ng], one["nd"].grad)
+        o_c, o_g = o_c + nc, o_g + ng

@@ -278,14 +278,21 @@ __global__ __launch_bounds__(kBlock) void spot_seed_kernel(int P, int W, const f
 // =================================================================== C ABI
 // Paraxial entrance-pupil position (the `z` argument of the trace): z = B/A of the ordered product
 // M = M_{K-1} ... M_0 of the rows in front of the stop, M_k = [[1 + P t, r t], [P, r]], r = n_k / n_{k+1},
-// P = c (r - 1)  (ray_tracing_lite.py:301-350, lens_modeling.py ABCD).  K <= 32 rows: one thread, fp64 inside.
+// P = c (r - 1)  (ray_tracing_lite.py:301-350, lens_modeling.py ABCD).  K <= 32 rows: one thread per lens, fp64 inside.
 // Replaces ~25 tiny elementwise / 2x2-matmul launches of the host chain and ~60 of its autograd backward.
-__global__ void pupil_position_kernel(int K, const float *__restrict__ c, const float *__restrict__ t,
-                                      const float *__restrict__ n, float *__restrict__ z,
-                                      const float *__restrict__ g_z, float *__restrict__ g_c,
-                                      float *__restrict__ g_t, float *__restrict__ g_n)
+// A batch of B lenses: c, t [B,K], n [B,K+1], z, g_z [B]; rows behind a lens' own stop are padded (c = 0, t = 0,
+// n = 1): identity matrices.
+__global__ __launch_bounds__(64) void pupil_position_kernel(int B, int K, const float *__restrict__ c,
+                                                            const float *__restrict__ t, const float *__restrict__ n,
+                                                            float *__restrict__ z, const float *__restrict__ g_z,
+                                                            float *__restrict__ g_c, float *__restrict__ g_t,
+                                                            float *__restrict__ g_n)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int lens = blockIdx.x * 64 + threadIdx.x;
+    if (lens >= B) return;
+    c += (size_t)lens * K; t += (size_t)lens * K; n += (size_t)lens * (K + 1);
+    if (z) z += lens;
+    if (g_z) { g_z += lens; g_c += (size_t)lens * K; g_t += (size_t)lens * K; g_n += (size_t)lens * (K + 1); }
     double R[TL_MAX_SURFACES][4];            // R[k] = M_{k-1} ... M_0 (row-major a b / c d), R[0] = I
     double a = 1.0, b = 0.0, cc = 0.0, d = 1.0;
     for (int k = 0; k < K; ++k) {
@@ -537,15 +544,15 @@ int tl_spot_seed(int32_t device, int32_t F, int32_t P, int32_t W, const float *x
     return TL_OK;
 }
 
-int tl_pupil_position(int32_t device, int32_t K, const float *c, const float *t, const float *n, float *z,
+int tl_pupil_position(int32_t device, int32_t B, int32_t K, const float *c, const float *t, const float *n, float *z,
                       const float *g_z, float *g_c, float *g_t, float *g_n, void *stream)
 {
-    if (K < 1 || K > TL_MAX_SURFACES || !c || !t || !n) return fail(TL_EINVAL, "tl_pupil_position: bad argument");
+    if (B < 1 || K < 1 || K > TL_MAX_SURFACES || !c || !t || !n) return fail(TL_EINVAL, "tl_pupil_position: bad argument");
     if (!z && !g_z) return fail(TL_EINVAL, "tl_pupil_position: neither z nor g_z given");
     if (g_z && (!g_c || !g_t || !g_n)) return fail(TL_EINVAL, "tl_pupil_position: g_z needs g_c, g_t and g_n");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-    hipLaunchKernelGGL(pupil_position_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, K, c, t, n, z, g_z, g_c, g_t, g_n);
+    hipLaunchKernelGGL(pupil_position_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, K, c, t, n, z, g_z, g_c, g_t, g_n);
     const int herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "pupil_position_kernel launch");
     return TL_OK;

@@ -337,20 +337,20 @@ class SpotMomentsFunction(torch.autograd.Function):
 
 
 class PupilPositionFunction(torch.autograd.Function):
-    """z [1] = paraxial entrance-pupil position from the rows in front of the stop: c, t [K], n [K+1]
-    (tl_pupil_position: one tiny kernel forward, one backward, fp64 inside)."""
+    """z [B] = paraxial entrance-pupil position from the rows in front of the stop: c, t [B,K], n [B,K+1]
+    (tl_pupil_position: one tiny kernel forward, one backward, one thread per lens, fp64 inside)."""
 
     @staticmethod
     def forward(ctx, c, t, n):
         for name, ten in (("c", c), ("t", t), ("n", n)):
             _require_device(ten, name)
-        K = c.numel()
-        c, t, n = (a.detach().to(torch.float32).reshape(-1).contiguous() for a in (c, t, n))
-        if t.numel() != K or n.numel() != K + 1:
-            raise ValueError("pupil position: c, t must hold K rows and n K+1 indices")
-        z = torch.empty(1, dtype=torch.float32, device=c.device)
+        B, K = c.shape
+        c, t, n = (a.detach().to(torch.float32).contiguous() for a in (c, t, n))
+        if t.shape != (B, K) or n.shape != (B, K + 1):
+            raise ValueError("pupil position: c, t must hold [B,K] rows and n [B,K+1] indices")
+        z = torch.empty(B, dtype=torch.float32, device=c.device)
         with torch.cuda.device(c.device):
-            rc = _lib.lib().tl_pupil_position(c.device.index, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), _lib.ptr(z),
+            rc = _lib.lib().tl_pupil_position(c.device.index, B, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), _lib.ptr(z),
                                               None, None, None, None, _stream_ptr(c.device))
         _lib.check(rc, "tl_pupil_position")
         ctx.save_for_backward(c, t, n)
@@ -359,13 +359,12 @@ class PupilPositionFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_z):
         c, t, n = ctx.saved_tensors
-        K = c.numel()
-        g_z = g_z.to(torch.float32).reshape(1).contiguous()
+        B, K = c.shape
+        g_z = g_z.to(torch.float32).reshape(B).contiguous()
         g_c, g_t, g_n = torch.empty_like(c), torch.empty_like(t), torch.empty_like(n)
         with torch.cuda.device(c.device):
-            rc = _lib.lib().tl_pupil_position(c.device.index, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), None,
+            rc = _lib.lib().tl_pupil_position(c.device.index, B, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), None,
                                               _lib.ptr(g_z), _lib.ptr(g_c), _lib.ptr(g_t), _lib.ptr(g_n),
                                               _stream_ptr(c.device))
         _lib.check(rc, "tl_pupil_position (backward)")
         return g_c, g_t, g_n
-

@@ -47,12 +47,11 @@ def compute_pupil_position(lens: Lens) -> torch.Tensor:
     if front.structure.mask.shape[1] == 0:
         return torch.zeros(len(front), dtype=lens.c.dtype, device=lens.c.device)
     n = _with_air_in_front(front.nd)
-    if front.c.is_cuda and len(front) == 1 and front.c.dtype == torch.float32:
-        # one lens on the GPU (the hot configuration): the whole chain below and its autograd backward are
-        # one tiny kernel each (tl_pupil_position, fp64 inside) instead of ~25 + ~60 launches
+    if front.c.is_cuda and front.c.dtype == torch.float32:
+        # on the GPU (the hot configuration): the whole chain below and its autograd backward are one tiny kernel
+        # each (tl_pupil_position, one thread per lens, fp64 inside) instead of ~25 + ~60 launches
         from . import ops
-        K = front.c.shape[1]
-        return ops.PupilPositionFunction.apply(front.c.reshape(K), front.t.reshape(K), n.reshape(K + 1)).to(lens.c.dtype)
+        return ops.PupilPositionFunction.apply(front.c, front.t, n).to(lens.c.dtype)
     m = reduce_abcd(interface_propagation_abcd(front.c, front.t, n))
     return m[:, 0, 1] / m[:, 0, 0]
 
