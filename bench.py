@@ -433,11 +433,13 @@ def main():
 
         # the reference's real caller as a minibatch: 256 lenses x 1 536 rays, aggregate + ray aiming, per-lens losses;
         # one batched launch each way against the caller's one-lens-at-a-time loop (examples/minibatch_loss.py)
-        log("lens minibatch")
+        log("lens minibatch (child process)")
         try:
-            sys.path.insert(0, os.path.join(ROOT, "examples"))
-            import minibatch_loss
-            also["lens_minibatch"] = minibatch_loss.run(256, 10, 16, 1, device=device, arith=a.mode)
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "minibatch_loss.py"), "--lenses", "256", "--steps", "20",
+                                 "--loop-lenses", "16", "--graph", "--mode", a.mode], capture_output=True, text=True, timeout=240)
+            line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            also["lens_minibatch"] = (json.loads(line[-1]) if cp.returncode == 0 and line
+                                      else dict(error=f"exit {cp.returncode}", stderr_tail=cp.stderr[-300:]))
         except Exception as e:
             also["lens_minibatch"] = dict(error=repr(e))
 

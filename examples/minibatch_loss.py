@@ -48,7 +48,7 @@ def build_batch(n_lens, device, seed=0):
     return st, specs, leaves, len(a["sequence"][0])
 
 
-def run(n_lens=256, steps=20, loop_lenses=32, aim=1, device="cuda:0", arith="strict"):
+def run(n_lens=256, steps=20, loop_lenses=32, aim=1, device="cuda:0", arith="strict", graph=False):
     import torchoptics_amd as ta
     from torchoptics_amd import ray_tracing as rt
     st, specs, leaves, n_seq = build_batch(n_lens, device)
@@ -56,9 +56,9 @@ def run(n_lens=256, steps=20, loop_lenses=32, aim=1, device="cuda:0", arith="str
                           n_ray_aiming_iter=aim, default_device=device, arith=arith)
     rays_per_lens = len(FIELDS) * RINGS * RINGS * len(WAVELENGTHS)
 
-    def batched_step():
-        leaves["c"].grad = leaves["t"].grad = None
-        lens = ta.Lens(st, leaves["c"], leaves["t"], leaves["nd"], leaves["v"])
+    def batched_step(lv=leaves):
+        lv["c"].grad = lv["t"].grad = None
+        lens = ta.Lens(st, lv["c"], lv["t"], lv["nd"], lv["v"])
         out = tracer.trace_rays(specs, lens, aggregate=True)
         ld = rt.unsupervised_loss_batch(out, n_seq, PENALTY_RATE)
         ld["loss_unsup"].sum().backward()
@@ -92,6 +92,37 @@ def run(n_lens=256, steps=20, loop_lenses=32, aim=1, device="cuda:0", arith="str
         return (time.perf_counter() - t0) / n, res
 
     t_b, ld = timed(batched_step, steps)
+    graph_res = None
+    if graph:
+        # the batched step recorded once into a HIP graph (see examples/adam_loop.py for why the warm-up runs on the
+        # capture stream); a training loop copies the generator's new c, t into the static leaves and replays
+        # Fresh leaves that only ever see the capture stream: a leaf's AccumulateGrad node remembers the stream it was
+        # created on, and one left over from the eager steps above (default stream) makes the autograd engine
+        # synchronise the capturing stream with the default stream -- hipStreamEndCapture then segfaults.
+        gl = dict(leaves, c=leaves["c"].detach().clone().requires_grad_(True), t=leaves["t"].detach().clone().requires_grad_(True))
+        cap = torch.cuda.Stream(device)
+        cap.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(cap):
+            for _ in range(3):
+                batched_step(gl)
+        torch.cuda.current_stream(device).wait_stream(cap)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            ld_g = batched_step(gl)
+        new_c, new_t = leaves["c"].detach().clone(), leaves["t"].detach().clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            with torch.no_grad():
+                gl["c"].copy_(new_c), gl["t"].copy_(new_t)              # "the generator's output of this step"
+            g.replay()
+        torch.cuda.synchronize()
+        t_g = (time.perf_counter() - t0) / steps
+        graph_res = dict(ms_per_step=t_g * 1e3, lenses_per_s=n_lens / t_g, M_rays_per_s=n_lens * rays_per_lens / t_g / 1e6,
+                         max_rel_loss_diff_vs_eager=float(((ld_g["loss_unsup"].detach() - ld["loss_unsup"].detach()).abs()
+                                                           / ld["loss_unsup"].detach().abs()).max()),
+                         grad_c_rel_diff_vs_eager=float((gl["c"].grad - leaves["c"].grad).norm() / leaves["c"].grad.norm()))
     t_l, l_loop = timed(looped_step, max(1, steps // 4))
     # the batch and the loop compute the same per-lens losses and gradients
     lb = ld["loss_unsup"].detach()[:loop_lenses]
@@ -106,6 +137,7 @@ def run(n_lens=256, steps=20, loop_lenses=32, aim=1, device="cuda:0", arith="str
         one_lens_at_a_time=dict(lenses=loop_lenses, ms_per_lens=t_l / loop_lenses * 1e3, lenses_per_s=loop_lenses / t_l,
                                 M_rays_per_s=loop_lenses * rays_per_lens / t_l / 1e6,
                                 note="the reference's caller's loop (optical_loss.py:96-110) through the same API, B = 1 per call"),
+        batched_hip_graph=graph_res,
         speedup=(n_lens / t_b) / (loop_lenses / t_l),
         max_rel_loss_diff=float(((lb - l_loop).abs() / l_loop.abs()).max()),
         grad_c_rel_diff=float((g_b - g_l).norm() / g_l.norm()),
@@ -120,5 +152,6 @@ if __name__ == "__main__":
     ap.add_argument("--loop-lenses", type=int, default=32)
     ap.add_argument("--aim", type=int, default=1)
     ap.add_argument("--mode", default="strict")
+    ap.add_argument("--graph", action="store_true", help="also replay the batched step from a HIP graph")
     a = ap.parse_args()
-    print(json.dumps(run(a.lenses, a.steps, a.loop_lenses, a.aim, arith=a.mode)))
+    print(json.dumps(run(a.lenses, a.steps, a.loop_lenses, a.aim, arith=a.mode, graph=a.graph)))

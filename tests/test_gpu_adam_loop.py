@@ -91,3 +91,17 @@ def test_whole_adam_step_with_ray_aiming_replays_from_a_hip_graph():
     g = _adam_child("--graph", "--steps", "6", "--aim", "1")
     e = _adam_child("--capturable", "--steps", "8", "--aim", "1")
     assert abs(g["loss_final"] - e["loss_final"]) <= 1e-6 * abs(e["loss_final"]), (g["loss_final"], e["loss_final"])
+
+
+def test_minibatch_of_lenses_batched_looped_and_replayed_from_a_graph():
+    """examples/minibatch_loss.py: the reference caller's minibatch (aggregate + ray aiming, per-lens loss_unsup) as one
+    batched launch, as the caller's one-lens-at-a-time loop, and replayed from a HIP graph: same losses, same gradients."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import minibatch_loss
+    r = minibatch_loss.run(n_lens=12, steps=3, loop_lenses=4, aim=1, graph=True)
+    assert r["max_rel_loss_diff"] <= 1e-6 and r["grad_c_rel_diff"] <= 1e-5
+    g = r["batched_hip_graph"]
+    assert g["max_rel_loss_diff_vs_eager"] == 0.0 and g["grad_c_rel_diff_vs_eager"] == 0.0
+    assert r["loss_mean"] > 0 and r["batched"]["lenses_per_s"] > r["one_lens_at_a_time"]["lenses_per_s"]

@@ -38,11 +38,23 @@ def tee(tensor=None, device="cuda"):
 def circle(tensor, n_r, n_theta, default_device="cuda"):
     """Polar grid: radii linspace(0,1,n_r) and angles linspace(0,2pi,n_theta), both without the
     end point -- so n_theta coincident rays at r=0 and none at r=1 (reference quirk B7, kept)."""
+    # the grid is a constant of (n_r, n_theta, device): small ones are kept, so that a step that builds its fan inside
+    # a captured HIP graph does no host-to-device copy (and an eager loop saves six launches per step)
+    key = (n_r, n_theta, str(default_device))
+    hit = _CIRCLE.get(key)
+    if hit is not None:
+        return hit
     r = torch.from_numpy(np.linspace(0, 1.0, n_r, endpoint=False, dtype=np.float32)).to(default_device)
     th = torch.from_numpy(np.linspace(0, 2 * np.pi, n_theta, endpoint=False, dtype=np.float32)).to(default_device)
     x = r[None, :, None] * torch.cos(th)[None, None, :]
     y = r[None, :, None] * torch.sin(th)[None, None, :]
-    return x.reshape(-1, 1, n_r * n_theta, 1), y.reshape(-1, 1, n_r * n_theta, 1)
+    out = x.reshape(-1, 1, n_r * n_theta, 1), y.reshape(-1, 1, n_r * n_theta, 1)
+    if n_r * n_theta <= (1 << 16) and len(_CIRCLE) < 16:
+        _CIRCLE[key] = out
+    return out
+
+
+_CIRCLE = {}
 
 
 def circle_index_range(n_r, n_theta, start, stop, default_device="cuda"):
@@ -282,7 +294,8 @@ def unsupervised_loss_batch(rt_outputs, n_sequence, penalty_rate: float):
         q = (torch.stack(stacks['theta_norm'], 0).sum(0) + torch.stack(stacks['theta_prime_norm'], 0).sum(0)
              + torch.stack(stacks['z_RELU'], 0).sum(0))
         q = torch.where(torch.isnan(q), torch.zeros_like(q), q).sum(dim=(1, 2, 3))
-    n_seq = torch.as_tensor(n_sequence, device=q.device, dtype=q.dtype)
+    # (a Python number divides without a host-to-device copy: the step can sit inside a captured HIP graph)
+    n_seq = n_sequence if isinstance(n_sequence, (int, float)) else torch.as_tensor(n_sequence, device=q.device, dtype=q.dtype)
     pen = (q / n_seq).to(torch.float32)
     return {'loss_unsup': rms + penalty_rate * pen, 'rms': rms, 'penalty': pen}
 
