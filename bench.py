@@ -230,18 +230,23 @@ def flops_per_ray(S, n_asph=0):
     """fp32 arithmetic operations per ray as written in csrc/tl_kernels.inc (mul, add/sub, sqrt, div,
     rcp, rsq each count 1, an FMA-able pair counts 2; compares, selects, negations, abs not counted; counted by
     hand from the source, see DESIGN.md "Flop counts").
-      spherical row : step_fwd 54 | walk-back (inverse refraction + intersection 51, partial recompute 17,
-                      adjoint 99) = 167 | checkpoint backward = forward sweep 54 + recompute 49 + adjoint 99
+      spherical row : step_fwd 54 | walk-back = inverse refraction 20 + intersection quantities shared between the
+                      forward step's e, m2, tmp and the back-intersection with the previous surface 47 + 3 reciprocals
+                      + adjoint with the per-row sums 82 = 152 | checkpoint backward = forward sweep 54 + recompute 49
+                      + adjoint 84
       aspheric row  : step_fwd_asph = sphere guess 27 + 2 Newton steps x 53 (the minimum: one step, plus the one
                       after the convergence vote) + converged sag / acceptance test 43 + vector Snell 36 = 212;
                       walk-back = aspheric normal + inverse vector Snell 55, Newton hit on that row from the next one
                       27 + 2 x 53 + 6 = 139, step_bwd_asph 238 + coefficient wave sums 14 = 446;
                       checkpoint backward = forward sweep 212 + step_bwd_asph 252
-    The Newton step count is data dependent; 2 per row is the floor, so aspheric flop rates are LOWER bounds."""
+    The Newton step count is data dependent; 2 per row is the floor, so aspheric flop rates are LOWER bounds.
+    (Round 2, second half: the adjoint was re-written with its factors of 2 and 1/2 folded by hand, -15 operations per
+    row, and the walk-back shares one dot product and one |h|^2 between the two intersections, -3: 167 -> 152 and
+    202 -> 187 per row; rates quoted before that change used the old counts.)"""
     sph = S - n_asph
     fwd = 54 * sph + 212 * n_asph + 5
-    bwd_ck = fwd + (49 + 99) * sph + 252 * n_asph + 30
-    bwd_inv = 167 * sph + 446 * n_asph + 40
+    bwd_ck = fwd + (49 + 84) * sph + 252 * n_asph + 30
+    bwd_inv = 152 * sph + 446 * n_asph + 40
     return fwd, bwd_ck, bwd_inv
 
 
