@@ -266,7 +266,7 @@ def roofline_of(job, kern_ms, mode):
         bwd_name = "trace_bwd_kernel"
     elif meta["n_asph"]:
         bwd_name = "trace_bwd_inv_kernel<true>"
-    elif 3 <= meta["S"] <= 12 and os.environ.get("TL_INV_ROLLED") != "1":
+    elif 3 <= meta["S"] <= 20 and meta["P_local"] >= 256 and os.environ.get("TL_INV_ROLLED") != "1":
         bwd_name = f"trace_bwd_inv_unrolled_kernel<{meta['S']}>"
     else:
         bwd_name = "trace_bwd_inv_kernel<false>"
