@@ -167,3 +167,53 @@ def test_aggregate_on_a_batch():
     tr = ta.RayTracer(mode="circular", n_rays=(8, 8), rel_fields=(0., 1.), wavelengths=("d",), default_device=DEV)
     out = tr.trace_rays(specs, lens, aggregate=True)
     assert len(out) == 7 and out[6]["theta_norm"][0].shape == (2, 2, 64, 1) and out[6].q_per_lens.shape == (2,)
+
+
+@pytest.mark.parametrize("algo", ["inverse", "checkpoint"])
+def test_batch_with_aspheric_rows_and_opd(algo):
+    """The extensions on a batch: per-lens conic / polynomial terms ([B,S], [B,S,4]) and the optical path length with
+    its gradient, against the oracle's trace_skew_general lens by lens (parity unpinned by the reference, which has no
+    aspheres: the oracle is the FD-checked definition, tests/test_oracle_asphere.py)."""
+    import torchoptics_amd as ta
+    from conftest import rel_l2
+    from oracle import trace_oracle as orc
+    from torchoptics_amd import ops
+    g, ins, mask = _g11(DEV)
+    B, S, W = 3, ins[5].shape[-1], ins[7].shape[3]
+    gen = torch.Generator().manual_seed(11)
+    kap = torch.zeros(B, S)
+    pol = torch.zeros(B, S, 4)
+    kap[0, 0], kap[1, 3], kap[2, 5] = -0.6, 0.4, -1.0
+    pol[0, 0, 0], pol[2, 5, 1], pol[1, 3, 0] = 2e-5, -2e-7, -3e-5
+    kind = (kap != 0) | (pol != 0).any(dim=-1)
+    n = [torch.ones(B, 1, 1, W)]
+    for k in range(S):
+        n.append(n[-1] / ins[7][..., k].cpu())
+    n_index = torch.stack(n, dim=-1)                                   # [B,1,1,W,S+1]
+    lv = [q.to(DEV).requires_grad_(True) for q in (ins[5].cpu(), ins[6].cpu(), kap, pol)]
+    w_opd = torch.rand(B, 3, 256, W, generator=gen).to(DEV)
+    ops.set_backward_algorithm(algo)
+    try:
+        out = ta.trace_skew(ins[0], ins[1], ins[2], ins[3], ins[4], lv[0], lv[1], ins[7], mask, kappa=lv[2], poly=lv[3],
+                            surf_kind=kind.to(DEV), n_index=n_index.to(DEV), want_opd=True)
+        loss = ta.compute_rms2d_batch(out[0], out[1], out[4]).sum() + 1e-3 * (out[6] * w_opd).sum()
+        loss.backward()
+    finally:
+        ops.set_backward_algorithm("inverse")
+    for b in range(B):
+        one = [a[b:b + 1].cpu().double() if a.shape[0] == B else a.cpu().double() for a in ins[:5]]
+        cb, tb = (ins[i][b:b + 1].cpu().double().requires_grad_(True) for i in (5, 6))
+        kb, pb = kap[b].double().requires_grad_(True), pol[b].double().requires_grad_(True)
+        o = orc.trace_skew_general(*one, cb, tb, ins[7][b:b + 1].cpu().double(), mask[b:b + 1].cpu(), kb, pb,
+                                   [int(v) for v in kind[b]], n_index=n_index[b:b + 1].double())
+        assert torch.equal(o[4], out[4][b:b + 1].cpu())
+        for i, tol in ((0, 3e-5), (1, 3e-5), (6, 1e-4)):
+            assert (o[i] - out[i][b:b + 1].cpu().double()).abs().max().item() <= tol, (b, i)
+        lb = orc.compute_rms2d(o[0], o[1], o[4]) + 1e-3 * (o[6] * w_opd[b:b + 1].cpu().double()).sum()
+        lb.backward()
+        for name, got, want in (("c", lv[0].grad[b], cb.grad[0]), ("t", lv[1].grad[b], tb.grad[0]), ("kappa", lv[2].grad[b], kb.grad),
+                                ("poly", lv[3].grad[b], pb.grad)):
+            if want.abs().max() == 0:
+                assert got.abs().max().item() == 0, (b, name)
+                continue
+            assert rel_l2(got.cpu().numpy(), want.numpy()) <= 1e-4, (algo, b, name, rel_l2(got.cpu().numpy(), want.numpy()))
