@@ -217,3 +217,23 @@ def test_batch_with_aspheric_rows_and_opd(algo):
                 assert got.abs().max().item() == 0, (b, name)
                 continue
             assert rel_l2(got.cpu().numpy(), want.numpy()) <= 1e-4, (algo, b, name, rel_l2(got.cpu().numpy(), want.numpy()))
+
+
+def test_batch_without_backward_rays_and_untagged_spot_sizes():
+    """allow_backward_rays=False on a padded batch (the per-lens sequence mask gates the backward-ray test,
+    ray_tracing_lite.py:626-632) against the IEEE oracle, bit for bit; and compute_rms2d_batch on tensors that did not
+    come straight from the trace (no fused moments attached) equals the fused value."""
+    import torchoptics_amd as ta
+    from oracle import trace_oracle as orc
+    g, ins, mask = _g11(DEV)
+    out = ta.trace_skew(*ins, mask, allow_backward_rays=False)
+    want = orc.trace_skew(*[a.cpu() for a in ins], mask.cpu(), False, False, ieee_sqrt=True)
+    assert all(torch.equal(out[i].cpu(), want[i]) for i in range(5))
+    assert not out[5].any() and not want[5].any()           # (the reference leaves `ray_backward` at its broadcast shape here)
+    assert (~want[4]).sum() > (~torch.from_numpy(g["ok"])).sum()          # rays that only the backward test removes
+    fused = ta.compute_rms2d_batch(out[0], out[1], out[4])
+    plain = ta.compute_rms2d_batch(out[0].clone(), out[1].clone(), out[4].clone())
+    assert fused.shape == (3,) and torch.allclose(fused, plain, rtol=1e-6, atol=0)
+    for b in range(3):
+        one = orc.compute_rms2d(want[0][b:b + 1], want[1][b:b + 1], want[4][b:b + 1])
+        assert abs(fused[b].item() - one.item()) <= 2e-5 * one.item()      # (the oracle sums in fp32, the kernel in fp64)
