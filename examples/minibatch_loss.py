@@ -94,22 +94,12 @@ def run(n_lens=256, steps=20, loop_lenses=32, aim=1, device="cuda:0", arith="str
     t_b, ld = timed(batched_step, steps)
     graph_res = None
     if graph:
-        # the batched step recorded once into a HIP graph (see examples/adam_loop.py for why the warm-up runs on the
-        # capture stream); a training loop copies the generator's new c, t into the static leaves and replays
-        # Fresh leaves that only ever see the capture stream: a leaf's AccumulateGrad node remembers the stream it was
-        # created on, and one left over from the eager steps above (default stream) makes the autograd engine
-        # synchronise the capturing stream with the default stream -- hipStreamEndCapture then segfaults.
-        gl = dict(leaves, c=leaves["c"].detach().clone().requires_grad_(True), t=leaves["t"].detach().clone().requires_grad_(True))
-        cap = torch.cuda.Stream(device)
-        cap.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(cap):
-            for _ in range(3):
-                batched_step(gl)
-        torch.cuda.current_stream(device).wait_stream(cap)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=cap):
-            ld_g = batched_step(gl)
+        # the batched step recorded once into a HIP graph, from fresh leaves that only ever see the capture stream
+        # (torchoptics_amd/graphs.py says why); a training loop copies the generator's new c, t into them and replays
+        from torchoptics_amd import graphs
+        gc_, gt_ = graphs.fresh_leaves(leaves["c"], leaves["t"])
+        gl = dict(leaves, c=gc_, t=gt_)
+        g, ld_g = graphs.capture_step(lambda: batched_step(gl), device)
         new_c, new_t = leaves["c"].detach().clone(), leaves["t"].detach().clone()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
