@@ -110,7 +110,25 @@ def test_cabi_error_codes(ta):
     assert lib.tl_trace_fwd(C.byref(p), *([None] * 8), _lib.ptr(mom), None, 0, None) == -3      # workspace too small
     p.surf_kind = m8.data_ptr()                                                     # kappa / poly missing
     assert lib.tl_trace_fwd(C.byref(p), *([None] * 9), None, 0, None) == -1
+    p.surf_kind = None
+    p.B = -1                                                                        # lens batch: B >= 0, B*F*W <= 65535
+    assert lib.tl_trace_fwd(C.byref(p), *([None] * 9), None, 0, None) == -1 and b"B must" in lib.tl_last_error()
+    p.B, p.F = 700, 100
+    assert lib.tl_trace_fwd(C.byref(p), *([None] * 9), None, 0, None) == -1 and b"65535" in lib.tl_last_error()
+    p.B, p.F = 0, 1                                                                 # B = 0 is read as one lens
+    assert lib.tl_workspace_bytes(C.byref(p)) > 0
     torch.cuda.synchronize()
+
+
+def test_empty_pupil(ta):
+    """P = 0 (an empty shard): empty per-ray outputs, zero moments, zero gradients, nothing launched."""
+    a = {k: v.to(DEV) for k, v in lens_args(ta, 7).items()}
+    c = a["c"].clone().requires_grad_(True)
+    x0, y0 = a["x"][:, :, :0], a["y"][:, :, :0]
+    out = ta.trace_skew(x0, y0, a["z"], a["cx"], a["cy"], c, a["t"], a["mu"], a["mask"])
+    assert out[0].shape[2] == 0 and out[4].numel() == 0
+    (out[1].sum() + out[0].sum()).backward()
+    assert c.grad is not None and not c.grad.any()
 
 
 def test_two_host_threads_share_the_library(ta):

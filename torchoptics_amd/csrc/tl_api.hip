@@ -84,7 +84,8 @@ int check_problem(const tl_problem *p)
     if (p->S > TL_MAX_SURFACES) return fail(TL_EINVAL, "S exceeds TL_MAX_SURFACES (32)");
     if (p->B < 0) return fail(TL_EINVAL, "B must be >= 0 (0 is read as 1)");
     if ((int64_t)lenses(p) * p->F * p->W > 65535) return fail(TL_EINVAL, "B*F*W exceeds 65535");
-    if (!p->x_in || !p->y_in || !p->z || !p->cx || !p->cy || !p->c || !p->t || !p->mu || !p->mask)
+    // (an empty shard, P = 0, has nothing to point x_in / y_in at: an empty tensor's data pointer is NULL)
+    if ((p->P > 0 && (!p->x_in || !p->y_in)) || !p->z || !p->cx || !p->cy || !p->c || !p->t || !p->mu || !p->mask)
         return fail(TL_EINVAL, "a required device pointer of tl_problem is NULL");
     if (p->mode != TL_MODE_STRICT && p->mode != TL_MODE_FAST) return fail(TL_EINVAL, "unknown mode");
     if ((p->cx_stride | 1) != 1 || (p->cy_stride | 1) != 1) return fail(TL_EINVAL, "cx/cy stride must be 0 or 1");
@@ -453,7 +454,8 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     int rc = check_problem(p);
     if (rc) return rc;
     if (!g_c || !g_t || !g_mu || !g_z || !g_cx || !g_cy) return fail(TL_EINVAL, "a parameter-gradient output is NULL");
-    if (!x_fwd || !y_fwd || !cx_fwd || !cy_fwd || !ok_fwd) return fail(TL_EINVAL, "the forward outputs x, y, cx, cy, ok are required");
+    if (p->P > 0 && (!x_fwd || !y_fwd || !cx_fwd || !cy_fwd || !ok_fwd))
+        return fail(TL_EINVAL, "the forward outputs x, y, cx, cy, ok are required");
     if (p->aggregate || !p->allow_backward)
         return fail(TL_EINVAL, "tl_trace_bwd_from_outputs: allow_backward_rays and no penalty term only");
     if ((g_kappa || g_poly) && !p->surf_kind) return fail(TL_EINVAL, "g_kappa / g_poly need aspheric rows (surf_kind)");
