@@ -232,3 +232,41 @@ def test_many_fields_and_wavelengths_small_pupil(ta):
     o = orc.trace_skew(*[(cc if k == "c" else a[k].double()) for k in order], a["mask"])
     orc.compute_rms2d(o[0], o[1], o[4]).backward()
     assert rel_l2(c.grad.cpu().numpy(), cc.grad.numpy()) < 2e-4
+
+
+def test_non_finite_prescription_behaves_like_the_reference(ta):
+    """A NaN curvature / an infinite gap: no hang, no fault; the same rays are flagged as in the oracle and the outputs
+    carry NaN in the same places (the reference's comparisons are false for NaN, so such rays are NOT retired)."""
+    from oracle import trace_oracle as orc
+    a = lens_args(ta, 7)
+    order = ("x", "y", "z", "cx", "cy", "c", "t", "mu")
+    for key, idx, val in (("c", 2, float("nan")), ("t", 3, float("inf")), ("mu", 1, float("nan"))):
+        b = {k: v.clone() for k, v in a.items()}
+        b[key][..., idx] = val
+        want = orc.trace_skew(*[b[k] for k in order], b["mask"], ieee_sqrt=True)
+        got = ta.trace_skew(*[b[k].to(DEV) for k in order], b["mask"].to(DEV))
+        assert torch.equal(got[4].cpu(), want[4]) and torch.equal(got[5].cpu(), want[5]), key
+        for i in range(4):
+            assert torch.equal(torch.isnan(got[i].cpu()), torch.isnan(want[i])), (key, i)
+            assert torch.allclose(got[i].cpu(), want[i], rtol=0, atol=0, equal_nan=True), (key, i)
+
+
+def test_cfg4_total_on_one_gpu(ta):
+    """2^27 rays (the whole cfg4 workload) through one launch each way: 64-bit indexing, R = 32 / 64 rays per lane."""
+    from torchoptics_amd import prescriptions as P, ray_tracing as rt
+    lens, specs, leaves = P.double_gauss(DEV)
+    tr = ta.RayTracer(mode="circular", n_rays=(8192, 16384), rel_fields=(0.707,), wavelengths=("d",), default_device=DEV)
+    x, y, cx, cy, ok, back = tr.trace_rays(specs, lens)
+    assert x.numel() == 1 << 27 and bool(ok.all())
+    rms = rt.compute_rms2d(x, y, ok)
+    rms.backward()
+    tr2 = ta.RayTracer(mode="circular", n_rays=(1024, 1024), rel_fields=(0.707,), wavelengths=("d",), default_device=DEV)
+    g_big = leaves["c"].grad.clone()
+    leaves["c"].grad = None
+    x2, y2, _, _, ok2, _ = tr2.trace_rays(specs, P.double_gauss(DEV)[0].__class__(lens.structure, leaves["c"], leaves["t"], leaves["nd"], leaves["v"]))
+    rms2 = rt.compute_rms2d(x2, y2, ok2)
+    rms2.backward()
+    assert abs(rms.item() - rms2.item()) <= 2e-3 * rms2.item()          # the same spot on a 128 x denser grid
+    assert rel_l2(g_big.cpu().numpy(), leaves["c"].grad.cpu().numpy()) < 5e-3
+    del x, y, cx, cy, ok, back
+    torch.cuda.empty_cache()
