@@ -94,6 +94,22 @@ class _Timed:
             _timing[self.key].append((self.a, self.b))
 
 
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CTX = _NoCtx()
+
+
+def _on_device(dev):
+    """`with torch.cuda.device(dev)` only when dev is not the current device already (the usual case: ~6 us saved)."""
+    return _NO_CTX if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Per-(device, stream) scratch for the block partials; grows monotonically."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -167,7 +183,7 @@ class TraceFunction(torch.autograd.Function):
         opd = torch.empty((B, F, W, P), dtype=torch.float32, device=dev) if want_opd else None
         stacks = torch.empty((3, S, B, F, W, P), dtype=torch.float32, device=dev) if (aggregate and want_stacks) else None
         moments = torch.empty((B * F, TL_NMOM), dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev), _Timed("fwd", dev):
+        with _on_device(dev), _Timed("fwd", dev):
             rc = lib.tl_trace_fwd(C.byref(prob), *[_lib.ptr(b) for b in fp], *[_lib.ptr(b) for b in bp],
                                   _lib.ptr(opd), _lib.ptr(stacks), _lib.ptr(moments), _lib.ptr(ws), ws.numel(),
                                   _stream_ptr(dev))
@@ -181,6 +197,7 @@ class TraceFunction(torch.autograd.Function):
         ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, *fwd_out,
                               n_index if want_opd else None)
         ctx.allow_back, ctx.mode, ctx.aggregate, ctx.use_inv = allow_back, mode, aggregate, use_inv
+        ctx.prob, ctx.ws_bytes = prob, nbytes      # same tensors, same pointers in backward: no need to fill it again
         ctx.set_materialize_grads(False)
         if want_rays:
             outs = [b.permute(0, 1, 3, 2) for b in fp]
@@ -209,9 +226,9 @@ class TraceFunction(torch.autograd.Function):
             return (None,) * n_in
         asph = kind_u8 is not None
         lib = _lib.lib()
-        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, ctx.allow_back, ctx.mode, kappa, poly, kind_u8,
-                        n_index if gopd is not None else None, aggregate=ctx.aggregate)
-        ws = _workspace(lib.tl_workspace_bytes(C.byref(prob)), dev)
+        prob = ctx.prob
+        prob.n_index = n_index.data_ptr() if gopd is not None else None
+        ws = _workspace(ctx.ws_bytes, dev)
 
         def dense(g):
             if g is None or g.numel() == 0:
@@ -228,7 +245,7 @@ class TraceFunction(torch.autograd.Function):
         parts = [new(B, S), new(B, S), new(B, W, S), new(B), new(B, F), new(B, F)]
         g_kappa, g_poly = (new(B, S), new(B, S, 4)) if asph else (None, None)
         g_n = new(B, W, S + 1) if gopdd is not None else None
-        with torch.cuda.device(dev), _Timed("bwd", dev):
+        with _on_device(dev), _Timed("bwd", dev):
             if ctx.use_inv:
                 rc = lib.tl_trace_bwd_from_outputs(
                     C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd), _lib.ptr(gmd),
@@ -272,7 +289,7 @@ class SpotRmsFunction(torch.autograd.Function):
         m = moments.to(torch.float64).contiguous()
         rms = torch.empty(() if n_lens == 1 else (n_lens,), dtype=torch.float32, device=dev)
         dm = torch.empty_like(m)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = _lib.lib().tl_spot_rms(dev.index, n_lens, m.shape[0] // n_lens, float(n_per_field), _lib.ptr(m),
                                         _lib.ptr(rms), _lib.ptr(dm), _stream_ptr(dev))
         _lib.check(rc, "tl_spot_rms")
@@ -309,7 +326,7 @@ class SpotMomentsFunction(torch.autograd.Function):
         lib = _lib.lib()
         moments = torch.empty((F, TL_NMOM), dtype=torch.float64, device=dev)
         ws = _workspace(F * W * ((P + 255) // 256) * TL_NMOM * 8 + 256, dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = lib.tl_spot_moments(dev.index, F, P, W, _lib.ptr(xs), _lib.ptr(y), _lib.ptr(oks),
                                      y.stride(1), y.stride(2), y.stride(3), _lib.ptr(moments),
                                      _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
@@ -328,7 +345,7 @@ class SpotMomentsFunction(torch.autograd.Function):
         gy = torch.empty_strided(y.shape, y.stride(), dtype=torch.float32, device=dev)
         need_x = ctx.has_x and ctx.needs_input_grad[0]
         gx = torch.empty_strided(y.shape, y.stride(), dtype=torch.float32, device=dev) if need_x else None
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = lib.tl_spot_seed(dev.index, F, P, W, _lib.ptr(xs) if ctx.has_x else None, _lib.ptr(y),
                                   _lib.ptr(oks), y.stride(1), y.stride(2), y.stride(3), _lib.ptr(gm),
                                   _lib.ptr(gx), _lib.ptr(gy), _stream_ptr(dev))
@@ -349,7 +366,7 @@ class PupilPositionFunction(torch.autograd.Function):
         if t.shape != (B, K) or n.shape != (B, K + 1):
             raise ValueError("pupil position: c, t must hold [B,K] rows and n [B,K+1] indices")
         z = torch.empty(B, dtype=torch.float32, device=c.device)
-        with torch.cuda.device(c.device):
+        with _on_device(c.device):
             rc = _lib.lib().tl_pupil_position(c.device.index, B, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), _lib.ptr(z),
                                               None, None, None, None, _stream_ptr(c.device))
         _lib.check(rc, "tl_pupil_position")
@@ -362,7 +379,7 @@ class PupilPositionFunction(torch.autograd.Function):
         B, K = c.shape
         g_z = g_z.to(torch.float32).reshape(B).contiguous()
         g_c, g_t, g_n = torch.empty_like(c), torch.empty_like(t), torch.empty_like(n)
-        with torch.cuda.device(c.device):
+        with _on_device(c.device):
             rc = _lib.lib().tl_pupil_position(c.device.index, B, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), None,
                                               _lib.ptr(g_z), _lib.ptr(g_c), _lib.ptr(g_t), _lib.ptr(g_n),
                                               _stream_ptr(c.device))

@@ -167,6 +167,20 @@ def _as_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t if t.dtype == torch.float32 else t.to(torch.float32)
 
 
+def _dense(a: torch.Tensor) -> torch.Tensor:
+    return a if a.is_contiguous() else a.contiguous()
+
+
+def _rows(a: torch.Tensor, n_lens: int, tail: tuple) -> torch.Tensor:
+    """[n_lens, *tail] contiguous from an argument that holds one set of values per lens, or one set for all."""
+    n_tail = 1
+    for d in tail:
+        n_tail *= d
+    if a.numel() == n_lens * n_tail:
+        return _dense(a.reshape(n_lens, *tail))
+    return _dense(a.reshape(1, *tail).expand(n_lens, *tail))
+
+
 def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_rays=True, mode=None,
                want_rays=True, kappa=None, poly=None, surf_kind=None, n_index=None, want_opd=False):
     """Trace rays from the entrance pupil to the image plane through S surface rows.
@@ -208,10 +222,12 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
     x_e, y_e = x.expand(B, F, P, W), y.expand(B, F, P, W)
     if any(a.shape[1] not in (1, F) or a.shape[2] != 1 or a.shape[3] != 1 for a in (cx, cy)):
         raise ValueError("cx, cy must be per-field [1|B,1|F,1,1]")
-    cx2, cy2 = cx.reshape(cx.shape[0], cx.shape[1]).contiguous(), cy.reshape(cy.shape[0], cy.shape[1]).contiguous()
-    zv = z.reshape(-1).expand(B).contiguous()
-    c2, t2 = c.reshape(-1, S).expand(B, S).contiguous(), t.reshape(-1, S).expand(B, S).contiguous()
-    mu3 = mu.reshape(mu.shape[0], mu.shape[3], S).expand(B, W, S).contiguous()
+    # (one view op per differentiable argument where the shapes allow: every reshape / expand of a leaf is a node the
+    #  autograd engine walks on the way back, ~5-10 us of host time each)
+    cx2, cy2 = _dense(cx.reshape(cx.shape[0], cx.shape[1])), _dense(cy.reshape(cy.shape[0], cy.shape[1]))
+    zv = _rows(z, B, ())
+    c2, t2 = _rows(c, B, (S,)), _rows(t, B, (S,))
+    mu3 = _rows(mu, B, (W, S)) if mu.shape[3] == W else _dense(mu.reshape(mu.shape[0], 1, S).expand(B, W, S))
     mask_u8 = mask.reshape(-1, S)
     mask_u8 = mask_u8.view(torch.uint8) if mask_u8.dtype == torch.bool else mask_u8.to(torch.uint8)   # bool: no copy
     mask_u8 = mask_u8.expand(B, S).contiguous()
