@@ -119,3 +119,22 @@ def test_full_loss_of_the_real_caller_on_the_two_asphere_double_gauss(ta):
     for k in ("c", "t", "nd", "kappa", "poly"):
         assert leaves[k].grad is not None and torch.isfinite(leaves[k].grad).all(), k
     assert leaves["kappa"].grad[1].abs().item() > 0 and leaves["kappa"].grad[10].abs().item() > 0
+
+
+def test_aggregate_sum_equals_aggregate_without_the_stacks(ta):
+    """aggregate='sum': the loss_dict and its gradients of aggregate=True, bit for bit, with no per-surface tensors
+    written (the reference's caller only ever sums them, optics_simulator_lite.py:441-448)."""
+    import yaml_free_lenses as L
+    from torchoptics_amd import ray_tracing as rt
+    res = {}
+    for agg in (True, "sum"):
+        lens, specs, leaves = L.build("cooke", DEV, epd=8.578)
+        tr = ta.RayTracer(mode="circular", n_rays=(8, 8), rel_fields=list(np.linspace(0, 1, 3)), wavelengths=[459., 520., 640.],
+                          n_ray_aiming_iter=1, default_device=DEV)
+        out = tr.trace_rays(specs, lens, aggregate=agg)
+        assert len(out) == 7 and (len(out[6]) == (3 if agg is True else 0))
+        ld = rt.unsupervised_loss(out, 7, 0.2)
+        grads = torch.autograd.grad(ld["loss_unsup"], [leaves[k] for k in ("c", "t", "nd")])
+        res[agg] = ([ld[k].item() for k in ("loss_unsup", "rms", "penalty")], [g.clone() for g in grads])
+    assert res[True][0] == res["sum"][0]
+    assert all(torch.equal(a, b) for a, b in zip(res[True][1], res["sum"][1]))

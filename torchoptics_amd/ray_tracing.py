@@ -194,7 +194,9 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
     Extras (not in the reference):
       aggregate   True: a 7th return value `stacks` = {'z_RELU', 'theta_norm', 'theta_prime_norm'}, each a
                   list of S tensors [1,F,P,W] as in the reference (:641-657).  The stacks are plain values;
-                  the differentiable quantity is their fused sum, see `penalty_sum(stacks, n_sequence)`;
+                  the differentiable quantity is their fused sum, see `penalty_sum(stacks, n_sequence)`.
+                  'sum': the same 7th value WITHOUT the per-surface tensors -- only the fused sums that
+                  `penalty_sum` / `unsupervised_loss` read (the lists are 12 S bytes of HBM writes per ray);
       mode        'strict' | 'fast' arithmetic (default ops.get_default_mode());
       kappa, poly aspheric rows: conic constants [S] and even polynomial terms [S,4] (a4..a10);
                   `surf_kind` [S] (bool/int) marks the rows traced by Newton iteration -- default: the
@@ -248,7 +250,7 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
         nidx = nidx.reshape(nidx.shape[0] if nidx.dim() == 5 else 1, -1, S + 1).expand(B, W, S + 1).contiguous()
     out = ops.TraceFunction.apply(x_e, y_e, zv, cx2, cy2, c2, t2, mu3, kap, pol, mask_u8, kind_u8, nidx,
                                   bool(allow_backward_rays), mode or ops.get_default_mode(), want_rays, bool(want_opd),
-                                  bool(aggregate), bool(aggregate and want_rays))
+                                  bool(aggregate), bool(aggregate is True and want_rays))
     xo, yo, cxo, cyo, ok, back, moments, opd, stk = out
     if want_rays:
         # remember which moments belong to these rays (checked by identity + version in compute_rms2d):
@@ -258,7 +260,7 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
         if want_opd:
             res += (opd,)
         if aggregate:
-            res += (PenaltyStacks(stk, moments),)
+            res += (PenaltyStacks(stk if aggregate is True else None, moments, B),)
         return res
     return moments
 
@@ -268,12 +270,12 @@ class PenaltyStacks(dict):
     `q_sum` = sum over all rays of (sum theta + sum theta' + sum z_RELU) with NaN -> 0, fused into the
     trace kernel and differentiable through its backward kernel (the lists themselves are values only)."""
 
-    def __init__(self, stk, moments):
+    def __init__(self, stk, moments, n_lens=1):
         super().__init__()
-        for j, key in enumerate(('z_RELU', 'theta_norm', 'theta_prime_norm')):
-            self[key] = list(torch.unbind(stk[j], dim=0))
+        if stk is not None:        # aggregate='sum': the fused sums only, no per-surface tensors (132 B per ray at 11 rows)
+            for j, key in enumerate(('z_RELU', 'theta_norm', 'theta_prime_norm')):
+                self[key] = list(torch.unbind(stk[j], dim=0))
         self.q_sum = moments[:, 8].sum()
-        n_lens = stk.shape[2] if stk.dim() == 6 else 1
         self.q_per_lens = moments[:, 8].view(n_lens, -1).sum(dim=1)      # lens batch: one penalty sum per lens
 
 
