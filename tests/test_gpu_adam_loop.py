@@ -95,12 +95,14 @@ def test_whole_adam_step_with_ray_aiming_replays_from_a_hip_graph():
 
 def test_minibatch_of_lenses_batched_looped_and_replayed_from_a_graph():
     """examples/minibatch_loss.py: the reference caller's minibatch (aggregate + ray aiming, per-lens loss_unsup) as one
-    batched launch, as the caller's one-lens-at-a-time loop, and replayed from a HIP graph: same losses, same gradients."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
-    import minibatch_loss
-    r = minibatch_loss.run(n_lens=12, steps=3, loop_lenses=4, aim=1, graph=True)
+    batched launch, as the caller's one-lens-at-a-time loop, and replayed from a HIP graph: same losses, same gradients.
+    (In a child process, like the other whole-step captures: a capture that goes wrong ends the process it runs in.)"""
+    import json
+    import subprocess
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "minibatch_loss.py"), "--lenses", "12", "--steps", "3",
+                         "--loop-lenses", "4", "--graph"], capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    r = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
     assert r["max_rel_loss_diff"] <= 1e-6 and r["grad_c_rel_diff"] <= 1e-5
     g = r["batched_hip_graph"]
     assert g["max_rel_loss_diff_vs_eager"] == 0.0 and g["grad_c_rel_diff_vs_eager"] == 0.0
