@@ -291,6 +291,22 @@ def roofline_of(job, kern_ms, mode):
     return roofline, valu, kernels, b_fwd + b_bwd
 
 
+def grad_report(job, group, backend, device):
+    """The leaf gradients the last step left behind (after the gradient all-reduce when sharded): values as seen by
+    rank 0, and whether every rank holds the same bits (all-gather of the packed vector, compared on every rank)."""
+    names = [k for k in LEAF_NAMES if k in job.args and job.args[k].grad is not None]
+    flat = torch.cat([job.args[k].grad.detach().reshape(-1).double() for k in names])
+    same = True
+    if group is not None:
+        world = torch.distributed.get_world_size(group)
+        src = flat.cpu() if backend == "gloo" else flat
+        got = [torch.empty_like(src) for _ in range(world)]
+        torch.distributed.all_gather(got, src, group=group)
+        same = all(torch.equal(g, got[0]) for g in got)
+    return dict(bitwise_equal_across_ranks=bool(same),
+                values={k: job.args[k].grad.detach().reshape(-1).cpu().tolist() for k in names})
+
+
 def summarize(job, times, steps):
     med = statistics.median(times)
     return dict(value=job.rays_total * steps / med / 1e6, unit="M rays/s", ms_per_step=med / steps * 1e3,
@@ -305,8 +321,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks ourselves (torch.distributed.run, one process per
+        # GPU) as a child process tree BEFORE this process has made any GPU call, pass rank 0's JSON line through
+        # and leave with the child's exit code
+        n_dev = torch.cuda.device_count()              # (counting devices does not initialise HIP)
+        if a.backend == "nccl" and a.gpus > n_dev:
+            raise SystemExit(f"--gpus {a.gpus} but this node shows {n_dev} GPU(s): RCCL needs one GPU per rank "
+                             "(--backend gloo rehearses several ranks on one GPU)")
+        from torchoptics_amd import dist as tl_dist
+        sys.stdout.flush()
+        raise SystemExit(tl_dist.spawn_local_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
     assert torch.cuda.is_available(), "bench.py needs an AMD GPU"
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -323,6 +348,7 @@ def main():
     meta = job.meta
     times, kern_ms, rms = timed(job, a.mode, a.steps, a.warmup, a.repeats, a.graph, a.backend, device)
     head = summarize(job, times, a.steps)
+    final_grads = grad_report(job, group, a.backend, device)
     roofline, roofline_valu, kernels, step_bpr = roofline_of(job, kern_ms, a.mode)
     inv = ops.get_backward_algorithm() == "inverse"
     solo = world == 1
@@ -474,6 +500,7 @@ def main():
             "step_hbm_GBs": job.rays_total * step_bpr / (head["ms_per_step"] * 1e6),
             "grad_rel_err_vs_pytorch_autograd": grad_check,
             "leaf_grads": leaf_grads,
+            "final_grads": final_grads,
             "other_mode": other,
             "hip_graph_replay": hip_graph,
             "also": also,

@@ -5,6 +5,7 @@ of the 20-row synthetic zoom, 5 fields x 3 wavelengths, every step = forward + R
 through the HIP kernels; the pupil is sharded over the GPUs of one node.
 
     python examples/adam_loop.py --steps 100                       # 1 GPU
+    python examples/adam_loop.py --steps 100 --gpus 8              # starts its own 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nproc-per-node 8 examples/adam_loop.py --steps 100
 
 The optimiser state lives on the device and nothing in the loop synchronises with the host except
@@ -116,7 +117,14 @@ def main():
     ap.add_argument("--capturable", action="store_true", help="eager loop with Adam(capturable=True): the arithmetic of the graph path")
     ap.add_argument("--aim", type=int, default=0, help="n_ray_aiming_iter (the reference's real caller uses 1)")
     ap.add_argument("--force-dist", action="store_true", help="initialise a 1-rank nccl (RCCL) group even when WORLD_SIZE=1")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to start (one per GPU) when not already under a launcher")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start the ranks ourselves, as a child process tree, before this process touches the GPU
+        if a.backend == "nccl" and a.gpus > torch.cuda.device_count():
+            raise SystemExit(f"--gpus {a.gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
+        from torchoptics_amd import dist as tl_dist
+        raise SystemExit(tl_dist.spawn_local_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     torch.cuda.set_device(local)

@@ -1,0 +1,55 @@
+"""`python bench.py --gpus 2` with no launcher around it: bench.py starts its own two ranks (torch.distributed.run as a
+child process tree, before the parent touches the GPU), both ranks run the HIP kernels on device 0 of the one-GPU box,
+each on its own half of the pupil grid, and exchange the spot moments and the leaf gradients through `gloo` (RCCL
+wants one GPU per rank; the collectives' shape and the sharding are the ones of the 8-GPU run).  The result must be
+the 1-rank run on the same 2x grid: same loss, same gradients, the same bits on both ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--steps", "3", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--no-other-mode", "--no-also",
+          "--no-sweep", "--no-graph-child"]
+
+
+def _run(cmd, timeout=420):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cp = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert cp.returncode == 0, f"{cmd} exited with {cp.returncode}\n{cp.stdout[-2000:]}\n{cp.stderr[-4000:]}"
+    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, cp.stdout[-2000:]          # rank 0 prints ONE line, the other rank nothing
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload", ["cfg3", "cfg3a"])
+def test_bench_starts_its_own_two_ranks_and_matches_the_one_rank_run(workload):
+    two = _run(["bench.py", "--gpus", "2", "--backend", "gloo", "--log2-pupil", "18", "--workload", workload] + COMMON)
+    one = _run(["bench.py", "--gpus", "1", "--log2-pupil", "19", "--workload", workload] + COMMON)
+    assert two["n_gpus"] == 2 and two["n_ranks_seen"] == 2 and two["config"]["collectives"] == "gloo"
+    assert one["n_gpus"] == 1 and one["n_ranks_seen"] == 1
+    assert f"{2 << 18} total" in two["config"]["workload"] and f"{1 << 19} total" in one["config"]["workload"]
+    # same grid, sharded in two: the moments are fp64 sums, the loss is replicated
+    assert abs(two["config"]["rms"] - one["config"]["rms"]) <= 1e-7 * abs(one["config"]["rms"]) + 1e-12
+    assert two["final_grads"]["bitwise_equal_across_ranks"]
+    for k, ref in one["final_grads"]["values"].items():
+        got, ref = np.asarray(two["final_grads"]["values"][k]), np.asarray(ref)
+        # (each rank rounds its fp64 sums to fp32 once before the exchange; d/dz and d/dcy of the inner and the outer
+        #  half of the pupil largely cancel, which amplifies that rounding)
+        tol = 1e-4 if k in ("z", "cy") else 2e-6
+        assert np.linalg.norm(got - ref) <= tol * np.linalg.norm(ref) + 1e-12, k
+
+
+def test_adam_loop_starts_its_own_two_ranks():
+    args = ["examples/adam_loop.py", "--steps", "5", "--log2-pupil", "12"]
+    a = _run(args + ["--gpus", "2", "--backend", "gloo"])
+    b = _run(args)
+    assert a["n_gpus"] == 2 and b["n_gpus"] == 1
+    # twice the rays on the same kind of grid is another fan: not the same loss, but the same optimisation behaviour
+    assert a["loss_final"] != a["loss_initial"] and b["loss_final"] != b["loss_initial"]

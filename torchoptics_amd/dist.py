@@ -28,16 +28,17 @@ def init_group(device, backend: str = "nccl", force: bool = False):
     on ROCm.  `force=True` builds the group even for WORLD_SIZE=1 (a 1-rank RCCL communicator on this GPU):
     every collective of the sharded path then really executes, which is how the path is exercised on a
     one-GPU box."""
-    import os
-    import socket
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and not force:
         return None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if "MASTER_PORT" not in os.environ:
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        # a port of our own choosing only works when nobody else has to find it: with several ranks each would
+        # bind a different one and the rendezvous would hang until its timeout
+        if world > 1:
+            raise RuntimeError("WORLD_SIZE > 1 but MASTER_PORT is unset: start the ranks with torch.distributed.run "
+                               "(or dist.spawn_local_ranks), which hands every rank the same rendezvous port")
+        os.environ["MASTER_PORT"] = str(free_port())
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
     if not dist.is_initialized():
@@ -46,6 +47,32 @@ def init_group(device, backend: str = "nccl", force: bool = False):
         else:
             dist.init_process_group(backend)
     return dist.group.WORLD
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_local_ranks(script: str, argv, n_ranks: int, timeout=None) -> int:
+    """Start `n_ranks` ranks of `script argv...` on this node with torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1) as a CHILD process and return its exit code; stdout / stderr are inherited, so rank
+    0's report goes straight through.  Must be called before the calling process has touched the GPU: a process
+    that has initialised HIP must never be replaced or forked into GPU work on this platform, which is why the
+    ranks are a fresh process tree and the caller only waits for them."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it here
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    return subprocess.run(cmd, env=env, timeout=timeout).returncode
 
 
 def ranks_seen(group, device) -> int:
