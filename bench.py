@@ -16,13 +16,14 @@ tiny all-reduce when N > 1].  The pupil coordinates are resident in HBM before t
 The K-step region is timed `--repeats` times (default 3) after ONE warm-up; `value` is the median.
 
 Workloads:
-  cfg3 (default): the ALL-SPHERICAL variant of BASELINE configs[2]: synthesized double Gauss, 11 rows
-        (10 refracting surfaces + stop), F=1 field (0.707), W=1 ('d'), circular pupil grid 4096 x 4096 =
-        2^24 rays PER GPU (weak scaling; at N=8 this is cfg4's 2^27 rays).  The variant whose arithmetic the
-        reference pins (it has no aspheres): the config BASELINE.json's metric is quoted on.
-  cfg3a: the same double Gauss with 2 aspheric rows (conic + a4, a6; Newton intersection) -- BASELINE
-        configs[2] as written; an extension beyond the reference (parity unpinned by it).  Reported with
-        its own roofline and gradient check under also.cfg3a of the default run.
+  cfg3a (default, the headline): BASELINE configs[2] AS WRITTEN -- synthesized double Gauss, 11 rows (10 refracting
+        surfaces + stop), 2 of them aspheric (conic + a4, a6; Newton intersection), F=1 field (0.707), W=1 ('d'),
+        circular pupil grid 4096 x 4096 = 2^24 rays PER GPU (weak scaling; at N=8 this is cfg4's 2^27 rays).
+        Aspheres are an extension beyond the reference (parity unpinned by it, pinned by the FD-checked oracle and by
+        analytic cases: stigmatic conic, Fermat).
+  cfg3: the ALL-SPHERICAL variant of the same lens -- the arithmetic the reference itself pins (bit-exact forward);
+        reported with its own roofline and gradient check under also.cfg3 of the default run.
+  cfg3s: cfg3a with STRONG aspheres (sag departure 0.32 / 0.11 mm, three Newton evaluations per row instead of two).
   cfg2: Cooke triplet (7 rows), 1024 x 1024 pupil, 3 fields, W=1.
   cfg5: 20-row synthetic zoom, 5 fields x 3 wavelengths, 1024 x 1024 pupil.
   sweep (default run, N=1): {2^20, 2^22, 2^24, 2^26} rays x {7, 11, 20} rows, F=W=1, fwd+bwd.
@@ -44,7 +45,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 LEAF_NAMES = ("z", "cy", "c", "t", "mu", "kappa", "poly")   # differentiable arguments of trace_skew
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector (every issue slot an FMA)
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")
 
 
 def parse():
@@ -53,7 +54,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=3, help="how often the K-step region is timed (value = median)")
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg3a", "cfg2", "cfg5"])
+    ap.add_argument("--workload", default="cfg3a", choices=["cfg3a", "cfg3", "cfg3s", "cfg2", "cfg5"])
     ap.add_argument("--mode", default=os.environ.get("TORCHOPTICS_AMD_MODE", "strict"), choices=["strict", "fast"])
     ap.add_argument("--log2-pupil", type=int, default=None, help="override log2 of pupil points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -78,8 +79,8 @@ def parse():
 # ------------------------------------------------------------------------------------------ workloads
 def build_lens(name, device):
     from torchoptics_amd import prescriptions as P
-    if name in ("cfg3", "cfg3a", "dg11"):
-        return P.double_gauss(device, aspheres=(name == "cfg3a"))
+    if name in ("cfg3", "cfg3a", "cfg3s", "dg11"):
+        return P.double_gauss(device, aspheres={"cfg3a": True, "cfg3s": "strong"}.get(name, False))
     if name in ("cfg2", "cooke7"):
         import yaml_free_lenses as L
         return L.build("cooke", device)
@@ -91,7 +92,8 @@ def workload(name, device, world, rank, log2_pupil, fields=None, wl=None):
     import torchoptics_amd as ta
     from torchoptics_amd import ray_tracing as rt
     lens, specs, leaves = build_lens(name, device)
-    dflt = {"cfg3": ((0.707,), ("d",), 24), "cfg3a": ((0.707,), ("d",), 24), "cfg2": ((0., 0.707, 1.), ("d",), 20),
+    dflt = {"cfg3": ((0.707,), ("d",), 24), "cfg3a": ((0.707,), ("d",), 24), "cfg3s": ((0.707,), ("d",), 24),
+            "cfg2": ((0., 0.707, 1.), ("d",), 20),
             "cfg5": (tuple(np.linspace(0, 1, 5)), ("C", "d", "F"), 20)}.get(name, ((0.707,), ("d",), 24))
     fields = fields or dflt[0]
     wl = wl or dflt[1]
@@ -246,7 +248,11 @@ def flops_per_ray(S, n_asph=0):
     sph = S - n_asph
     fwd = 54 * sph + 212 * n_asph + 5
     bwd_ck = fwd + (49 + 84) * sph + 252 * n_asph + 30
-    bwd_inv = 152 * sph + 446 * n_asph + 40
+    # round 3: the walk-back over an aspheric row reads the forward's stored hit instead of iterating (139 -> sag at the
+    # stored point 17 + distance along the line 8 = 25) and feeds the adjoint with the normal it already has
+    # (step_bwd_asph 238 -> asph_adjoint 186; aspheric normal + inverse vector Snell 47; quad sums of the five
+    # coefficient terms 8): 266 per aspheric row, whatever the strength of the asphere
+    bwd_inv = 152 * sph + 266 * n_asph + 40
     return fwd, bwd_ck, bwd_inv
 
 
@@ -258,18 +264,19 @@ def roofline_of(job, kern_ms, mode):
     inv = ops.get_backward_algorithm() == "inverse"
     # algorithmic bytes per ray (DESIGN.md "bytes per unit"): forward writes x,y,cx,cy,ok,back and reads x_in,y_in;
     # the walk-back backward reads x_in,y_in and the forward's x,y,cx,cy,ok; the checkpoint backward only x_in,y_in
-    b_fwd, b_bwd = 18.0 + 8.0 / fw, (17.0 if inv else 0.0) + 8.0 / fw
+    # (+ 8 bytes per ray and aspheric row each way: the hit points the forward leaves for the walk-back, tl_problem.asph_hits)
+    hit_b = 8.0 * min(meta["n_asph"], ops.ASPH_HIT_SLOTS) if (inv and meta["n_asph"] <= ops.ASPH_HIT_SLOTS) else 0.0
+    b_fwd, b_bwd = 18.0 + 8.0 / fw + hit_b, (17.0 + hit_b if inv else 0.0) + 8.0 / fw
     f_fwd, f_ck, f_inv = flops_per_ray(meta["S"], meta["n_asph"])
     f_bwd = f_inv if inv else f_ck
     # the walk-back kernel launch_bwd_inv picks (csrc/tl_kernels.inc: kInvUnrollMin / kInvUnrollMax)
+    unrolled = 3 <= meta["S"] <= 20 and meta["P_local"] >= 256 and os.environ.get("TL_INV_ROLLED") != "1"
     if not inv:
         bwd_name = "trace_bwd_kernel"
-    elif meta["n_asph"]:
-        bwd_name = "trace_bwd_inv_kernel<true>"
-    elif 3 <= meta["S"] <= 20 and meta["P_local"] >= 256 and os.environ.get("TL_INV_ROLLED") != "1":
-        bwd_name = f"trace_bwd_inv_unrolled_kernel<{meta['S']}>"
+    elif unrolled and (not meta["n_asph"] or hit_b):
+        bwd_name = f"trace_bwd_inv_unrolled_kernel<{meta['S']}, {'true' if meta['n_asph'] else 'false'}, false>"
     else:
-        bwd_name = "trace_bwd_inv_kernel<false>"
+        bwd_name = f"trace_bwd_inv_kernel<{'true' if meta['n_asph'] else 'false'}>"
     kernels = {}
     for key, bpr, fpr in (("fwd", b_fwd, f_fwd), ("bwd", b_bwd, f_bwd)):
         ms = kern_ms.get(key)
@@ -287,7 +294,7 @@ def roofline_of(job, kern_ms, mode):
                          "HBM bytes per launch from the committed rocprofv3 PMC passes, null for sizes not profiled")
     valu = dict(kernel=bwd_name, bound="valu_fp32", achieved=dom["valu_TFLOPs"], peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=dom["valu_TFLOPs"] / VALU_PEAK_TFLOPS,
-                note="aspheric rows counted at the 2-Newton-step floor: a lower bound" if meta["n_asph"] else None)
+                note="walk-back over stored hits: no Newton iteration in this kernel, the count is exact" if meta["n_asph"] else None)
     return roofline, valu, kernels, b_fwd + b_bwd
 
 
@@ -364,8 +371,8 @@ def main():
 
     # secondary workloads, same protocol, reported under "also" (N = 1 only: they are not part of the scaling run)
     also = {}
-    if solo and not a.no_also and a.workload == "cfg3" and a.log2_pupil is None:
-        for wname in ("cfg3a", "cfg2", "cfg5"):
+    if solo and not a.no_also and a.workload == "cfg3a" and a.log2_pupil is None:
+        for wname in ("cfg3", "cfg3s", "cfg2", "cfg5"):
             log(f"also: {wname}")
             j2 = Job(wname, device, world, rank, group)
             t2, km2, r2 = timed(j2, a.mode, a.steps, a.warmup, a.repeats, a.graph, a.backend, device)
@@ -376,14 +383,13 @@ def main():
                 # small workloads are bound by the eager Python/autograd chain, not by the GPU: what the two trace
                 # kernels alone sustain, and (hip_graph_value, from the graph child) what a recorded step reaches
                 e["trace_kernels_only_value"] = j2.rays_total / (km2["fwd"] + km2["bwd"]) / 1e3
-            if wname == "cfg3a" and not a.graph:
-                # BASELINE configs[2] as written: the full evidence of a headline line
+            if wname in ("cfg3", "cfg3s") and not a.graph:
+                # the all-spherical variant (the arithmetic the reference pins) and the strong-asphere variant: the
+                # full evidence of a headline line
                 rf, rv, kk, _ = roofline_of(j2, km2, a.mode)
-                e.update(roofline=rf, roofline_valu=rv, kernels=kk,
-                         workload="cfg3a: double Gauss with 2 aspheric rows (BASELINE configs[2] as written), S=11 rows, "
-                                  "F=1 W=1 P=2^24, circular grid, loss=compute_rms2d, fwd+bwd")
+                e.update(roofline=rf, roofline_valu=rv, kernels=kk, workload=workload_label(wname, j2.meta, j2))
                 if not a.no_cpu_baseline:
-                    log("also: cfg3a gradient check against the oracle (CPU)")
+                    log(f"also: {wname} gradient check against the oracle (CPU)")
                     _, e["grad_rel_err_vs_pytorch_autograd"] = cpu_leg(j2.args, j2.meta, min(a.cpu_log2_rays, 18), a.mode,
                                                                        time_it=False)
             also[wname] = e
@@ -392,7 +398,7 @@ def main():
 
     # north_star sweep: 1-64 M rays x 7 / 11 / 20 rows, one field, one wavelength, fwd+bwd
     sweep = None
-    if solo and not a.no_sweep and a.workload == "cfg3" and a.log2_pupil is None:
+    if solo and not a.no_sweep and a.workload == "cfg3a" and a.log2_pupil is None:
         sweep = []
         for lens_name, rows in (("cooke7", 7), ("dg11", 11), ("zoom20", 20)):
             log(f"sweep: {rows} rows")
@@ -445,7 +451,7 @@ def main():
     # BASELINE configs[4]: the 100-step Adam loop on the 20-row zoom (5 fields x 3 wavelengths, 2^20 pupil points per
     # GPU), every step = Lens assembly + dispersion + pupil position + forward + RMS + backward + Adam; eager and with
     # the whole step replayed from a HIP graph (child processes: examples/adam_loop.py is the harness)
-    if solo and group is None and not a.graph and not a.no_also and a.workload == "cfg3" and a.log2_pupil is None:
+    if solo and group is None and not a.graph and not a.no_also and a.workload == "cfg3a" and a.log2_pupil is None:
         import subprocess
         log("cfg5 Adam loop (child processes)")
         adam = {}
@@ -519,8 +525,10 @@ def step_bpr_of(job):
 
 def workload_label(name, meta, job):
     what = {"cfg3": "ALL-SPHERICAL variant of BASELINE configs[2] (double Gauss, no aspheric rows: the arithmetic the "
-                    "reference pins; the 2-asphere variant as written is under also.cfg3a)",
-            "cfg3a": "BASELINE configs[2] as written: double Gauss with 2 aspheric rows (extension, parity unpinned by the reference)",
+                    "reference itself pins)",
+            "cfg3a": "BASELINE configs[2] as written: double Gauss with 2 aspheric rows (aspheres are an extension: parity "
+                     "unpinned by the reference, pinned by the oracle and analytic cases; the all-spherical variant is under also.cfg3)",
+            "cfg3s": "BASELINE configs[2] with STRONG aspheres (sag departure 0.32 / 0.11 mm: 3 Newton evaluations per row)",
             "cfg2": "BASELINE configs[1]: Cooke triplet", "cfg5": "BASELINE configs[4] lens: 20-row zoom"}[name]
     return (f"{name}: {what}; S={meta['S']} rows, F={meta['F']} W={meta['W']} P={meta['P_local']} pupil points per GPU "
             f"({job.rays_local} rays/GPU, {job.rays_total} total), circular grid, loss=compute_rms2d, fwd+bwd")
@@ -713,7 +721,7 @@ def leaf_grad_check(name, device, mode, log2_pupil=18):
     import torchoptics_amd as ta
     from oracle import trace_oracle as orc
     from torchoptics_amd import ray_tracing as rt
-    dflt = {"cfg3": ((0.707,), ("d",)), "cfg3a": ((0.707,), ("d",)), "cfg2": ((0., 0.707, 1.), ("d",)),
+    dflt = {"cfg3": ((0.707,), ("d",)), "cfg3a": ((0.707,), ("d",)), "cfg3s": ((0.707,), ("d",)), "cfg2": ((0., 0.707, 1.), ("d",)),
             "cfg5": (tuple(np.linspace(0, 1, 5)), ("C", "d", "F"))}[name]
     fields, wl = dflt
     n_r = 1 << (log2_pupil // 2)

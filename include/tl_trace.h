@@ -27,10 +27,11 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 12
+#define TL_ABI_VERSION 13
 #define TL_MAX_SURFACES 32       /* rows per lens the backward kernels are built for */
 #define TL_NMOM 10               /* per-field sums, see tl_trace_fwd */
 #define TL_MAX_POLY 4            /* even aspheric terms a4,a6,a8,a10 */
+#define TL_MAX_HIT_SLOTS 8       /* aspheric rows per lens whose hit points tl_trace_fwd can hand to the walk-back */
 
 enum {
     TL_OK = 0,
@@ -83,6 +84,16 @@ typedef struct tl_problem {
     int32_t B;                   /* lenses in this launch; 0 is read as 1.  B * F * W <= 65535 */
     int32_t cx_stride_b, cy_stride_b;   /* element stride of cx / cy over the lens index (0 = shared) */
     int64_t xs_b, ys_b;          /* element stride of x_in / y_in over the lens index (0 = shared) */
+    /* ---- ABI 13 ---- */
+    float *asph_hits;            /* [asph_hit_slots][2][B,F,W,P] float, nullable: the hit point (X, Y) of every ray on the
+                                    j-th aspheric row of its lens, j < asph_hit_slots -- WRITTEN by tl_trace_fwd, READ by
+                                    tl_trace_bwd_from_outputs, which then needs no Newton iteration on the reversed ray (and
+                                    re-anchors the reconstruction at every aspheric row).  8 bytes per ray and aspheric row.
+                                    A lens with more aspheric rows than slots is still traced correctly: its backward falls
+                                    back, on the device, to the checkpoint kernel.  NULL: Newton on the reversed ray. */
+    int32_t asph_hit_slots;      /* 0..TL_MAX_HIT_SLOTS */
+    int32_t moments_x;           /* 1: tl_trace_fwd also accumulates the x-moments 4..6 (compute_rms2d reads y only:
+                                    ray_tracing_lite.py:684-701); 0: they are returned as 0 */
 } tl_problem;
 
 int         tl_version(void);            /* == TL_ABI_VERSION */
@@ -159,9 +170,16 @@ int tl_trace_bwd(const tl_problem *p,
  *   - `moments_fwd` (the forward's moments, nullable) counts an ill-conditioned live ray, or
  *   - the walk-back met a non-finite adjoint (it then flags a word at the end of the workspace).
  * Pass `moments_fwd` whenever it is available: without it an ill-conditioned fan is walked back anyway.
- * allow_backward = 1 and aggregate = 0 only, no OPD gradient (TL_EINVAL otherwise: use tl_trace_bwd).  Aspheric rows are walked
- * back too (Newton on the reversed ray; g_kappa, g_poly as in tl_trace_bwd, required iff p->surf_kind).
+ * allow_backward = 1 only, no OPD gradient (TL_EINVAL otherwise: use tl_trace_bwd).  Aspheric rows are walked
+ * back too (g_kappa, g_poly as in tl_trace_bwd, required iff p->surf_kind).
  * Workspace: tl_workspace_bytes(p); its contents need not be initialised.
+ * Recorded into a HIP graph, the call is replayed with the same internal token: give the tl_trace_fwd of the same
+ * step the SAME workspace with its full tl_workspace_bytes(p) (with or without `moments`) -- it clears the flag word, so
+ * that one replay that had to fall back does not pin every later replay to the (exact, slower) checkpoint kernel.
+ * Penalty term (p->aggregate, ABI 13): walked back too for lenses of 3..20 rows -- the rays alive at the image plane by
+ * the walk-back kernel, the rays that died on the way (they keep the gradient of the rows they passed alive) by the
+ * checkpoint kernel in the same call; other lenses are handed to tl_trace_bwd as a whole.  Aspheric rows (ABI 13): with
+ * p->asph_hits filled by tl_trace_fwd the hit on an aspheric row is read instead of searched.
  */
 int tl_trace_bwd_from_outputs(const tl_problem *p,
                               const float *gx, const float *gy, const float *gcx, const float *gcy,

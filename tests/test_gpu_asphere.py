@@ -47,18 +47,31 @@ def test_newton_rows_on_spherical_data_match_closed_form_kernel(ta, mode):
     assert (a[2] - b[2]).abs().max().item() < 2e-6 and (a[3] - b[3]).abs().max().item() < 2e-6
 
 
-@pytest.mark.parametrize("algo", ["inverse", "checkpoint"])
+def _algo(ops, algo):
+    """'inverse' = walk-back over stored hits (default), 'inverse_hits8' = the same with a slot for each of the 7 Newton
+    rows of the all-Newton Tessar, 'inverse_newton' = no stored hits: Newton on the reversed ray, 'checkpoint'."""
+    ops.set_backward_algorithm("checkpoint" if algo == "checkpoint" else "inverse")
+    ops.set_asph_hit_slots({"inverse_newton": 0, "inverse_hits8": 8}.get(algo, 4))
+
+
+def _algo_reset(ops):
+    ops.set_backward_algorithm("inverse")
+    ops.set_asph_hit_slots(4)
+
+
+@pytest.mark.parametrize("algo", ["inverse", "inverse_hits8", "inverse_newton", "checkpoint"])
 def test_newton_rows_everywhere_give_the_spherical_gradients(ta, algo):
     """Every row but the flat stop traced by Newton with zero conic / polynomial terms: first row, last row and
-    consecutive aspheric rows in the backward (walk-back: hit_asph at the start, between neighbours and into the
-    launch conditions).  The gradients w.r.t. c, t, mu must equal the closed-form lens's."""
+    consecutive aspheric rows in the backward (walk-back: stored hits / hit_asph at the start, between neighbours and
+    into the launch conditions; 'inverse' has 4 slots for 7 Newton rows: the device-side fallback to the checkpoint
+    kernel).  The gradients w.r.t. c, t, mu must equal the closed-form lens's."""
     from torchoptics_amd import ops
     ins, mask = _inputs()
     S = ins[5].shape[-1]
     kind = torch.ones(S, dtype=torch.bool)
     kind[4] = False
     grads = {}
-    ops.set_backward_algorithm(algo)
+    _algo(ops, algo)
     try:
         for tag in ("sph", "newton"):
             dev = [a.to(DEV) for a in ins]
@@ -66,11 +79,11 @@ def test_newton_rows_everywhere_give_the_spherical_gradients(ta, algo):
             extra = {} if tag == "sph" else dict(kappa=torch.zeros(S, device=DEV), poly=torch.zeros(S, 4, device=DEV),
                                                  surf_kind=kind)
             x, y, cx, cy, ok, back = ta.trace_skew(*dev[:5], *lv, mask.to(DEV), **extra)
-            assert x.grad_fn.use_inv is (algo == "inverse")
+            assert x.grad_fn.use_inv is (algo != "checkpoint")
             ta.compute_rms2d(x, y, ok).backward()
             grads[tag] = [q.grad.cpu().numpy() for q in lv]
     finally:
-        ops.set_backward_algorithm("inverse")
+        _algo_reset(ops)
     for n, a, b in zip(("c", "t", "mu"), grads["newton"], grads["sph"]):
         assert np.isfinite(a).all() and rel_l2(a, b) < 2e-5, f"{algo} d/d{n}: {rel_l2(a, b):.2e}"
 
@@ -98,11 +111,11 @@ def test_asphere_forward_matches_oracle(ta, case):
     assert not got[0].cpu()[~ok_g].any()
 
 
-@pytest.mark.parametrize("algo", ["inverse", "checkpoint"])
+@pytest.mark.parametrize("algo", ["inverse", "inverse_newton", "checkpoint"])
 @pytest.mark.parametrize("mode", ["strict", "fast"])
 def test_asphere_gradients_match_oracle_autograd(ta, algo, mode):
-    """Both backward algorithms on aspheric rows: the walk-back (Newton on the reversed ray, default) and the
-    checkpoint kernel, against the oracle's fp64 autograd."""
+    """The backward algorithms on aspheric rows: the walk-back over the forward's stored hit points (default), the
+    walk-back with Newton on the reversed ray, and the checkpoint kernel, against the oracle's fp64 autograd."""
     from oracle import trace_oracle as orc
     from torchoptics_amd import ops
     ins, mask = _inputs()
@@ -119,14 +132,14 @@ def test_asphere_gradients_match_oracle_autograd(ta, algo, mode):
         res[tag] = [q.grad for q in lv]
     lv = [ins[2], ins[4], ins[5], ins[6], ins[7], kap0, pol0]
     lv = [q.to(DEV).requires_grad_(True) for q in lv]
-    ops.set_backward_algorithm(algo)
+    _algo(ops, algo)
     try:
         x, y, cx, cy, ok, back = ta.trace_skew(ins[0].to(DEV), ins[1].to(DEV), lv[0], ins[3].to(DEV), lv[1], lv[2],
                                                lv[3], lv[4], mask.to(DEV), kappa=lv[5], poly=lv[6], mode=mode)
-        assert x.grad_fn.use_inv is (algo == "inverse")
+        assert x.grad_fn.use_inv is (algo != "checkpoint")
         ta.compute_rms2d(x, y, ok).backward()
     finally:
-        ops.set_backward_algorithm("inverse")
+        _algo_reset(ops)
     tol = 2e-5 if mode == "strict" else 2e-4
     for n, q, g32, g64 in zip(names, lv, res["f32"], res["f64"]):
         got = q.grad.cpu()
@@ -310,3 +323,50 @@ def test_conditioning_count_covers_aspheric_and_opd_rows(ta):
             ops.set_backward_algorithm("inverse")
     for a, b in zip(grads["inverse"], grads["checkpoint"]):
         assert torch.equal(a, b)
+
+
+def test_more_aspheric_rows_than_hit_slots_fall_back_on_the_device(ta):
+    """Two aspheric rows, one hit slot: the walk-back kernel flags the launch and the checkpoint kernel queued behind
+    it does the work -- the same bits as asking for the checkpoint algorithm."""
+    from torchoptics_amd import ops
+    ins, mask = _inputs()
+    S = ins[5].shape[-1]
+    kap0, pol0, kind = asphere_params(S)
+    grads = {}
+    for tag, algo, slots in (("one_slot", "inverse", 1), ("checkpoint", "checkpoint", 4), ("two_slots", "inverse", 2)):
+        ops.set_backward_algorithm(algo)
+        ops.set_asph_hit_slots(slots)
+        try:
+            lv = [q.to(DEV).clone().requires_grad_(True) for q in (ins[5], ins[6], ins[7], kap0, pol0)]
+            o = ta.trace_skew(*[a.to(DEV) for a in ins[:5]], lv[0], lv[1], lv[2], mask.to(DEV), kappa=lv[3], poly=lv[4])
+            ta.compute_rms2d(o[0], o[1], o[4]).backward()
+            grads[tag] = [q.grad.clone() for q in lv]
+        finally:
+            _algo_reset(ops)
+    for a, b, c in zip(grads["one_slot"], grads["checkpoint"], grads["two_slots"]):
+        assert torch.equal(a, b)
+        assert not torch.equal(c, b) and rel_l2(c.cpu().numpy(), b.cpu().numpy()) < 2e-5      # the walk-back did run there
+
+
+def test_lens_batch_with_aspheric_rows_walks_back_over_stored_hits(ta):
+    """B = 2 lenses with different aspheric rows (rows 0, 5 and row 2) in ONE launch each way: per-lens slots of the hit
+    buffer; gradients equal to the two lenses traced one at a time."""
+    ins, mask = _inputs()
+    S = ins[5].shape[-1]
+    kap0, pol0, _ = asphere_params(S)
+    kap1, pol1 = torch.zeros(S), torch.zeros(S, 4)
+    kap1[2], pol1[2, 0] = 0.3, 1e-5
+    kap, pol = torch.stack([kap0, kap1]), torch.stack([pol0, pol1])
+
+    def run(sel):
+        rep = lambda a: a.expand(len(sel), *a.shape[1:]).contiguous()      # noqa: E731
+        lv = [rep(ins[i]).to(DEV).requires_grad_(True) for i in (5, 6, 7)]
+        k, p_ = kap[sel].to(DEV).requires_grad_(True), pol[sel].to(DEV).requires_grad_(True)
+        o = ta.trace_skew(*[a.to(DEV) for a in ins[:5]], *lv, mask.to(DEV), kappa=k, poly=p_)
+        assert o[0].grad_fn.use_inv
+        from torchoptics_amd import ray_tracing as rt
+        rt.compute_rms2d_batch(o[0], o[1], o[4]).sum().backward()
+        return [q.grad.cpu() for q in (*lv, k, p_)]
+    both, first, second = run([0, 1]), run([0]), run([1])
+    for g2, ga, gb in zip(both, first, second):
+        assert torch.equal(g2[0], ga[0]) and torch.equal(g2[1], gb[0])

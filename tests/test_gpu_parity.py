@@ -266,13 +266,17 @@ def test_cfg2_full_size_scalars(ta):
         assert e64 < 5e-5, f"d/d{k} vs fp64: {e64:.2e}"
 
 
-def test_two_dimensional_rms_extension(ta):
-    """compute_rms_spot_xy (x- and y-moments from the kernel) vs the same statistic formed with plain
-    torch ops on the per-ray outputs, and its gradient vs autograd through the dense-gradient path."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_two_dimensional_rms_extension(ta, fused):
+    """compute_rms_spot_xy (x- and y-moments from the kernel when the trace was asked for them, a second pass over the
+    rays otherwise) vs the same statistic formed with plain torch ops on the per-ray outputs, and its gradient vs
+    autograd through the dense-gradient path."""
     from torchoptics_amd import ray_tracing as rt
     g = load_golden("G5_cooke_failures")
     ins, mask, allow = dev_inputs(g, grad=True)
-    x, y, cx, cy, ok, back = ta.trace_skew(*ins, mask, False, allow)
+    x, y, cx, cy, ok, back = ta.trace_skew(*ins, mask, False, allow, x_moments=fused)
+    mom = y._tl_spot[0]
+    assert (mom[:, 4:7].abs().sum().item() > 0) is fused          # x-moments only when asked for
     got = rt.compute_rms_spot_xy(x, y, ok)
     n = y.shape[2] * y.shape[3]
     okd, xd, yd = ok[0].double(), x[0].double(), y[0].double()
@@ -509,3 +513,28 @@ def test_full_size_properties(ta, wl):
         want = 0.7 * a.double() - 1.9 * b.double()
         scale = (0.7 * a.double().abs() + 1.9 * b.double().abs()).max().item()        # fp32 rounding of the terms
         assert (c_.double() - want).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("aggregate", [False, "sum"])
+def test_backward_under_saved_tensor_hooks(ta, aggregate):
+    """the backward reuses the tl_problem filled in forward; under saved-tensor hooks (save_on_cpu,
+    activation checkpointing) the unpacked tensors live in OTHER storage, so the problem must be rebuilt from them.
+    One step under torch.autograd.graph.save_on_cpu() gives the gradients of the plain step, bit for bit."""
+    from torchoptics_amd import ray_tracing as rt
+    g = load_golden("G4_tessar_32x32")
+    res = []
+    for hooks in (False, True):
+        ins, mask, allow = dev_inputs(g)
+        for q in ins[5:]:
+            q.requires_grad_(True)                  # c, t, mu only: the walk-back backward
+        ctxm = torch.autograd.graph.save_on_cpu() if hooks else torch.enable_grad()
+        with ctxm:
+            out = ta.trace_skew(*ins, mask, aggregate, allow)
+            assert out[0].grad_fn.use_inv
+            loss = ta.compute_rms2d(out[0], out[1], out[4])
+            if aggregate:
+                loss = loss + 0.2 * rt.penalty_sum(out[6], 8)
+        loss.backward()
+        res.append([q.grad.clone() for q in ins[5:]])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -138,3 +138,52 @@ def test_aggregate_sum_equals_aggregate_without_the_stacks(ta):
         res[agg] = ([ld[k].item() for k in ("loss_unsup", "rms", "penalty")], [g.clone() for g in grads])
     assert res[True][0] == res["sum"][0]
     assert all(torch.equal(a, b) for a, b in zip(res[True][1], res["sum"][1]))
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_penalty_walk_back_takes_the_live_rays_and_the_checkpoint_pass_the_dead_ones(ta, mode):
+    """The real caller's loss rms + 0.2 sumQ on a fan where every 7th ray starts far outside the aperture: those rays die
+    at rows 0..3 and keep the penalty gradient of the rows they passed alive, while no LIVE ray is ill-conditioned -- so
+    the default backward is the walk-back kernel for the live rays + the checkpoint kernel over the dead ones, summed by
+    the reduction.  Against the checkpoint algorithm for every ray and against the oracle's fp64 autograd."""
+    from oracle import trace_oracle as orc
+    from torchoptics_amd import ops, ray_tracing as rt
+    g = load_golden("G4_tessar_32x32")
+    ins = [torch.from_numpy(g[n]) for n in IN]
+    mask = torch.from_numpy(g["in_mask"])
+    F, P, W, S = ins[4].shape[1], ins[0].shape[2], ins[7].shape[3], ins[5].shape[-1]
+    x_in, y_in = ins[0].expand(1, F, P, W).clone(), ins[1].expand(1, F, P, W).clone()
+    x_in[:, :, ::7] *= 6.0
+    y_in[:, :, ::7] *= 6.0
+    names = ("z", "cy", "c", "t", "mu")
+    res = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        lv = [ins[i].to(dt).clone().requires_grad_(True) for i in (2, 4, 5, 6, 7)]
+        o = orc.trace_skew(x_in.to(dt), y_in.to(dt), lv[0], ins[3].to(dt), lv[1], lv[2], lv[3], lv[4], mask, True, True,
+                           ieee_sqrt=(dt == torch.float32))
+        (orc.compute_rms2d(o[0], o[1], o[4]) + 0.2 * orc.penalty_from_stacks(o[6], S)).backward()
+        res[tag] = [q.grad for q in lv]
+        ok_ref = o[4]
+    assert 0.05 < (~ok_ref).float().mean().item() < 0.2          # the fan has dead rays ...
+    got = {}
+    for algo in ("inverse", "checkpoint"):
+        ops.set_backward_algorithm(algo)
+        try:
+            lv = [ins[i].to(DEV).clone().requires_grad_(True) for i in (2, 4, 5, 6, 7)]
+            o = ta.trace_skew(x_in.to(DEV), y_in.to(DEV), lv[0], ins[3].to(DEV), lv[1], lv[2], lv[3], lv[4], mask.to(DEV),
+                              "sum", True, mode=mode)
+            assert o[0].grad_fn.use_inv is (algo == "inverse")
+            assert o[1]._tl_spot[0][:, 9].sum().item() == 0      # ... and no ill-conditioned live ray: the walk-back runs
+            (ta.compute_rms2d(o[0], o[1], o[4]) + 0.2 * rt.penalty_sum(o[6], S)).backward()
+            got[algo] = [q.grad.cpu() for q in lv]
+        finally:
+            ops.set_backward_algorithm("inverse")
+    tol = 1e-4 if mode == "strict" else 5e-4
+    for n, a, b, g32, g64 in zip(names, got["inverse"], got["checkpoint"], res["f32"], res["f64"]):
+        e_ck, e64, noise = rel_l2(a.numpy(), b.numpy()), rel_l2(a.numpy(), g64.numpy()), rel_l2(g32.numpy(), g64.numpy())
+        print(f"penalty walk-back {mode} d/d{n}: vs checkpoint {e_ck:.2e}, vs fp64 {e64:.2e} (oracle fp32 itself {noise:.2e})")
+        assert not torch.equal(a, b)                             # two different algorithms did the work
+        # (two fp32 evaluations of a gradient whose own fp32 noise is `noise`: near normal incidence d theta / d cos^2 is
+        #  ~2000 and fp32 autograd itself is 1e-4 from fp64, see the module docstring)
+        lim = tol if n in ("c", "t", "mu") else 2e-3
+        assert e_ck <= lim + 2 * noise and e64 <= lim + 2 * noise, f"{mode} d/d{n}: {e_ck:.2e} / {e64:.2e}"

@@ -12,10 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TORCHOPTICS_AMD_LIB: another build of the same library (an A/B variant written by build.build_library(tag=...))
 LIB_PATH = os.environ.get("TORCHOPTICS_AMD_LIB") or os.path.join(_HERE, "libtltrace.so")
 
-TL_ABI_VERSION = 12
+TL_ABI_VERSION = 13
 TL_NMOM = 10
 TL_MAX_SURFACES = 32
 TL_MAX_POLY = 4
+TL_MAX_HIT_SLOTS = 8
 MODE_STRICT, MODE_FAST = 0, 1
 
 
@@ -32,6 +33,7 @@ class tl_problem(C.Structure):
         ("kappa", C.c_void_p), ("poly", C.c_void_p), ("surf_kind", C.c_void_p), ("n_index", C.c_void_p),
         ("B", C.c_int32), ("cx_stride_b", C.c_int32), ("cy_stride_b", C.c_int32),
         ("xs_b", C.c_int64), ("ys_b", C.c_int64),
+        ("asph_hits", C.c_void_p), ("asph_hit_slots", C.c_int32), ("moments_x", C.c_int32),
     ]
 
 

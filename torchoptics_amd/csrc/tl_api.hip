@@ -92,6 +92,8 @@ int check_problem(const tl_problem *p)
     if ((p->surf_kind != nullptr) != (p->kappa != nullptr) || (p->surf_kind != nullptr) != (p->poly != nullptr))
         return fail(TL_EINVAL, "surf_kind, kappa and poly must be given together (or all NULL)");
     if (p->aggregate && p->S > 31) return fail(TL_EINVAL, "aggregate needs S <= 31");
+    if (p->asph_hit_slots < 0 || p->asph_hit_slots > TL_MAX_HIT_SLOTS) return fail(TL_EINVAL, "asph_hit_slots must be 0..TL_MAX_HIT_SLOTS");
+    if (p->asph_hits && p->asph_hit_slots == 0) return fail(TL_EINVAL, "asph_hits given with asph_hit_slots = 0");
     return TL_OK;
 }
 
@@ -145,18 +147,24 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
                                                             const double *__restrict__ alt_part, int alt_NS,
                                                             const double *__restrict__ fmom,
                                                             const unsigned *__restrict__ poison,
-                                                            unsigned token, int alt_nbx, float *__restrict__ g_n)
+                                                            unsigned token, int alt_nbx, float *__restrict__ g_n,
+                                                            int add_alt)
 {
     __shared__ double sm[kBlock];
     // two candidate partial arrays (walk-back kernel / checkpoint fallback): the forward's conditioning count
     // and the walk-back's poison word (== this call's token) say which of the two launches did the work (same rule as
-    // fallback_needed in tl_kernels.inc)
+    // fallback_needed in tl_kernels.inc).  add_alt (penalty term): when the walk-back did its work, the checkpoint
+    // launch behind it took the rays that died on the way -- the result is the SUM of the two arrays.
+    const double *part2 = nullptr;
+    int NS2 = 0, nbx2 = 0;
     if (alt_part) {
         double n = 0.0;
         if (fmom)
             for (int f = 0; f < F * (int)gridDim.y; ++f) n += fmom[(size_t)f * TL_NMOM + 9];
         if (n > 0.0 || (poison && *poison == token)) {
             part = alt_part; NS = alt_NS; ncol = tl_bwd_row(alt_NS, g_kappa != nullptr); nbx = alt_nbx;
+        } else if (add_alt) {
+            part2 = alt_part; NS2 = alt_NS; nbx2 = alt_nbx;
         }
     }
     // one block per output scalar: g_c[S] | g_t[S] | g_mu[W,S] | g_z | g_cx[F] | g_cy[F] [| g_kappa[S] | g_poly[S,4]] [| g_n[W,S+1]]
@@ -167,24 +175,29 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
     if (g_n) g_n += lens * W * (S + 1);
     int b = blockIdx.x;
     float *out;
-    int col, f0 = 0, nf = F, w0 = 0, nw = W;
+    // column = a * NS + c0 in a partial array whose rows were written for NS surface rows
+    int ca, c0, f0 = 0, nf = F, w0 = 0, nw = W;
     const int n_asph = g_kappa ? 5 * S : 0;
-    if (b < S) { col = b; out = g_c + b; }
-    else if ((b -= S) < S) { col = NS + b; out = g_t + b; }
-    else if ((b -= S) < W * S) { const int w = b / S, k = b % S; col = 2 * NS + k; w0 = w; nw = 1; out = g_mu + b; }
-    else if ((b -= W * S) < 1) { col = 3 * NS; out = g_z; }
-    else if ((b -= 1) < F) { col = 3 * NS + 1; f0 = b; nf = 1; out = g_cx + b; }
-    else if ((b -= F) < F) { col = 3 * NS + 2; f0 = b; nf = 1; out = g_cy + b; }
+    if (b < S) { ca = 0; c0 = b; out = g_c + b; }
+    else if ((b -= S) < S) { ca = 1; c0 = b; out = g_t + b; }
+    else if ((b -= S) < W * S) { const int w = b / S, k = b % S; ca = 2; c0 = k; w0 = w; nw = 1; out = g_mu + b; }
+    else if ((b -= W * S) < 1) { ca = 3; c0 = 0; out = g_z; }
+    else if ((b -= 1) < F) { ca = 3; c0 = 1; f0 = b; nf = 1; out = g_cx + b; }
+    else if ((b -= F) < F) { ca = 3; c0 = 2; f0 = b; nf = 1; out = g_cy + b; }
     else if ((b -= F) < n_asph) {                                                        // aspheric rows only
-        if (b < S) { col = 3 * NS + 3 + b; out = g_kappa + b; }
-        else { col = 4 * NS + 3 + (b - S); out = g_poly + (b - S); }                     // b - S = 4k + j
+        if (b < S) { ca = 3; c0 = 3 + b; out = g_kappa + b; }
+        else { ca = 4; c0 = 3 + (b - S); out = g_poly + (b - S); }                       // b - S = 4k + j
     } else {                                                                             // g_n[w][k], k <= S (OPD gradient only)
         b -= n_asph;
         const int w = b / (S + 1), k = b % (S + 1);
-        col = (g_kappa ? 8 : 3) * NS + 3 + k; w0 = w; nw = 1; out = g_n + b;
+        ca = g_kappa ? 8 : 3; c0 = 3 + k; w0 = w; nw = 1; out = g_n + b;
     }
     (void)ncol;
-    const double s = sum_rows(part, (int64_t)gridDim.y * F * W * nbx, col, W, nbx, lens * F + f0, nf, w0, nw, sm);
+    double s = sum_rows(part, (int64_t)gridDim.y * F * W * nbx, ca * NS + c0, W, nbx, lens * F + f0, nf, w0, nw, sm);
+    if (part2) {
+        __syncthreads();                          // sm is reused
+        s += sum_rows(part2, (int64_t)gridDim.y * F * W * nbx2, ca * NS2 + c0, W, nbx2, lens * F + f0, nf, w0, nw, sm);
+    }
     if (threadIdx.x == 0) *out = (float)s;        // summed in fp64, rounded once
 }
 
@@ -395,6 +408,10 @@ int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, 
         hipLaunchKernelGGL(reduce_moments_kernel, dim3(lenses(p) * p->F * TL_NMOM), dim3(kBlock), 0, st, part, moments, p->W, pl.nbx, clear);
         herr = (int)hipGetLastError();
         if (herr) return hip_fail(herr, "reduce_moments_kernel launch");
+    } else if (workspace && workspace_bytes >= tl_workspace_bytes(p)) {
+        // no moments, so no reduction kernel to clear the walk-back's poison word for a replayed step: clear it here
+        hipError_t e2 = hipMemsetAsync(poison_word(p, workspace), 0, sizeof(unsigned), st);
+        if (e2 != hipSuccess) return hip_fail(e2, "hipMemsetAsync(poison word)");
     }
     return TL_OK;
 }
@@ -438,7 +455,7 @@ int tl_trace_bwd(const tl_problem *p, const float *gx, const float *gy, const fl
     const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0) + (g_opd ? p->W * (p->S + 1) : 0);
     hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout, lenses(p)), dim3(kBlock), 0, st, part, ns, p->F, p->W, p->S, pl.nbx, g_c,
                        g_t, g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly, (const double *)nullptr, 0,
-                       (const double *)nullptr, (const unsigned *)nullptr, 0u, 0, g_n_index);
+                       (const double *)nullptr, (const unsigned *)nullptr, 0u, 0, g_n_index, 0);
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");
     return TL_OK;
@@ -456,8 +473,14 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     if (!g_c || !g_t || !g_mu || !g_z || !g_cx || !g_cy) return fail(TL_EINVAL, "a parameter-gradient output is NULL");
     if (p->P > 0 && (!x_fwd || !y_fwd || !cx_fwd || !cy_fwd || !ok_fwd))
         return fail(TL_EINVAL, "the forward outputs x, y, cx, cy, ok are required");
-    if (p->aggregate || !p->allow_backward)
-        return fail(TL_EINVAL, "tl_trace_bwd_from_outputs: allow_backward_rays and no penalty term only");
+    if (!p->allow_backward)
+        return fail(TL_EINVAL, "tl_trace_bwd_from_outputs: allow_backward_rays only");
+    const bool hits_ok = p->surf_kind == nullptr || (p->asph_hits != nullptr && p->asph_hit_slots > 0);
+    // the penalty term is walked back by the unrolled kernels only (3..20 rows, aspheric rows with stored hits);
+    // other lenses take the checkpoint kernel for every ray
+    if (p->aggregate && !(tl_walk_unrolled(p->S, p->P) && hits_ok))
+        return tl_trace_bwd(p, gx, gy, gcx, gcy, g_moments, nullptr, g_c, g_t, g_mu, g_z, g_cx, g_cy, g_kappa, g_poly,
+                            nullptr, g_x_in, g_y_in, workspace, workspace_bytes, stream);
     if ((g_kappa || g_poly) && !p->surf_kind) return fail(TL_EINVAL, "g_kappa / g_poly need aspheric rows (surf_kind)");
     if (p->surf_kind && (!g_kappa || !g_poly)) return fail(TL_EINVAL, "aspheric rows need g_kappa and g_poly outputs");
     if (p->P == 0) return tl_trace_bwd(p, gx, gy, gcx, gcy, g_moments, nullptr, g_c, g_t, g_mu, g_z, g_cx, g_cy, g_kappa, g_poly,
@@ -490,7 +513,7 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0);
     hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout, lenses(p)), dim3(kBlock), 0, st, part, p->S, p->F, p->W, p->S, pl.nbx, g_c, g_t,
                        g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly, (const double *)part_ck, ns,
-                       moments_fwd, (const unsigned *)poison, token, pk.nbx, (float *)nullptr);
+                       moments_fwd, (const unsigned *)poison, token, pk.nbx, (float *)nullptr, p->aggregate ? 1 : 0);
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");
     return TL_OK;

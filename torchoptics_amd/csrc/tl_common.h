@@ -18,6 +18,12 @@ static inline int tl_bwd_bucket(int S)
 // g_c | g_t | g_mu [NS each] | g_z g_cx g_cy | [g_kappa[NS] | g_poly[NS][4]] | g_n[NS+1]
 __host__ __device__ static inline int tl_bwd_row(int ns, bool asph) { return (asph ? 8 : 3) * ns + 3 + ns + 1; }
 
+// Row counts the walk-back kernel is instantiated for with its row loop unrolled (trace_bwd_inv_unrolled_kernel), and
+// the smallest pupil it takes (no skip there for waves past the end of a small pupil).
+#define TL_INVU_MIN 3
+#define TL_INVU_MAX 20
+static inline bool tl_walk_unrolled(int S, int P) { return S >= TL_INVU_MIN && S <= TL_INVU_MAX && P >= 256; }
+
 // per-mode launchers (defined in tl_strict.hip / tl_fast.hip); return hipError_t as int
 #define TL_DECLARE_MODE(NS)                                                                          \
     namespace NS {                                                                                   \

@@ -120,8 +120,22 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+# hit-point slots handed to the walk-back kernel per lens (tl_problem.asph_hits): lenses with more aspheric rows than
+# this still get the right gradient, from the checkpoint kernel (decided on the device, no host sync on the row kinds)
+ASPH_HIT_SLOTS = 4
+
+
+def set_asph_hit_slots(n: int) -> None:
+    """Hit-point slots per lens for the walk-back over aspheric rows (0.._lib.TL_MAX_HIT_SLOTS); 0 = no stored hits:
+    Newton iteration on the reversed ray (trace_bwd_inv_kernel<true>)."""
+    global ASPH_HIT_SLOTS
+    if not 0 <= int(n) <= _lib.TL_MAX_HIT_SLOTS:
+        raise ValueError(f"hit slots must be 0..{_lib.TL_MAX_HIT_SLOTS}")
+    ASPH_HIT_SLOTS = int(n)
+
+
 def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa=None, poly=None, kind_u8=None,
-             n_index=None, aggregate=False):
+             n_index=None, aggregate=False, hits=None, moments_x=False):
     B, F, P, W = x_e.shape
     p = tl_problem()
     p.F, p.P, p.W, p.S = F, P, W, c.shape[-1]
@@ -145,6 +159,9 @@ def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa=Non
     p.poly = poly.data_ptr() if asph else None
     p.surf_kind = kind_u8.data_ptr() if asph else None
     p.n_index = n_index.data_ptr() if n_index is not None else None
+    p.asph_hits = hits.data_ptr() if hits is not None else None
+    p.asph_hit_slots = hits.shape[0] if hits is not None else 0
+    p.moments_x = 1 if moments_x else 0
     return p
 
 
@@ -162,7 +179,7 @@ class TraceFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_e, y_e, z, cx, cy, c, t, mu, kappa, poly, mask_u8, kind_u8, n_index, allow_back, mode,
-                want_rays, want_opd, aggregate, want_stacks):
+                want_rays, want_opd, aggregate, want_stacks, moments_x=False):
         for name, ten in (("x", x_e), ("y", y_e), ("z", z), ("cx", cx), ("cy", cy), ("c", c), ("t", t),
                           ("mu", mu), ("mask", mask_u8)):
             _require_device(ten, name)
@@ -172,7 +189,17 @@ class TraceFunction(torch.autograd.Function):
         if S > _lib.TL_MAX_SURFACES:
             raise RuntimeError(f"lens has {S} rows; this build supports at most {_lib.TL_MAX_SURFACES}")
         lib = _lib.lib()
-        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa, poly, kind_u8, n_index, aggregate)
+        # per-ray input gradients (ray aiming: a handful of rays) keep the checkpoint algorithm: extreme rays
+        # amplify the reconstruction rounding of the walk-back to ~1e-4 in d/dx_in, d/dy_in
+        # ... and so does the gradient through the optical path length (only the checkpoint kernel carries it)
+        use_inv = (_bwd_algo == "inverse" and want_rays and allow_back and not want_opd
+                   and not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
+        # aspheric rows: the forward leaves their hit points for the walk-back (8 B per ray and slot actually used)
+        hits = None
+        if use_inv and kind_u8 is not None and ASPH_HIT_SLOTS > 0 and any(ctx.needs_input_grad[2:10]):
+            hits = torch.empty((min(ASPH_HIT_SLOTS, S), 2, B, F, W, P), dtype=torch.float32, device=dev)
+        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa, poly, kind_u8, n_index, aggregate,
+                        hits, moments_x)
         nbytes = lib.tl_workspace_bytes(C.byref(prob))
         ws = _workspace(nbytes, dev)
         if want_rays:
@@ -188,14 +215,9 @@ class TraceFunction(torch.autograd.Function):
                                   _lib.ptr(opd), _lib.ptr(stacks), _lib.ptr(moments), _lib.ptr(ws), ws.numel(),
                                   _stream_ptr(dev))
         _lib.check(rc, "tl_trace_fwd")
-        # per-ray input gradients (ray aiming: a handful of rays) keep the checkpoint algorithm: extreme rays
-        # amplify the reconstruction rounding of the walk-back to ~1e-4 in d/dx_in, d/dy_in
-        # ... and so does the gradient through the optical path length (only the checkpoint kernel carries it)
-        use_inv = (_bwd_algo == "inverse" and want_rays and not aggregate and allow_back and not want_opd
-                   and not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         fwd_out = (fp[0], fp[1], fp[2], fp[3], bp[0], moments) if use_inv else (None,) * 6
         ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, *fwd_out,
-                              n_index if want_opd else None)
+                              n_index if want_opd else None, hits)
         ctx.allow_back, ctx.mode, ctx.aggregate, ctx.use_inv = allow_back, mode, aggregate, use_inv
         ctx.prob, ctx.ws_bytes = prob, nbytes      # same tensors, same pointers in backward: no need to fill it again
         ctx.set_materialize_grads(False)
@@ -215,11 +237,11 @@ class TraceFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gx, gy, gcx, gcy, _gok, _gback, gmom, gopd, _gstk):
         (x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, fx, fy, fcx, fcy, fok, fmom,
-         n_index) = ctx.saved_tensors
+         n_index, hits) = ctx.saved_tensors
         dev = x_e.device
         B, F, P, W = x_e.shape
         S = c.shape[-1]
-        n_in = 19
+        n_in = 20
         if gopd is not None and (n_index is None or gopd.numel() == 0):
             gopd = None
         if gx is None and gy is None and gcx is None and gcy is None and gmom is None and gopd is None:
@@ -227,6 +249,11 @@ class TraceFunction(torch.autograd.Function):
         asph = kind_u8 is not None
         lib = _lib.lib()
         prob = ctx.prob
+        # saved-tensor hooks (save_on_cpu, checkpointing) hand back tensors in other storage than the forward saw
+        if (prob.x_in != (x_e.data_ptr() or None) or prob.c != c.data_ptr() or prob.mu != mu.data_ptr()
+                or prob.asph_hits != (hits.data_ptr() if hits is not None else None)):
+            prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, ctx.allow_back, ctx.mode, kappa, poly, kind_u8, None,
+                            ctx.aggregate, hits, False)
         prob.n_index = n_index.data_ptr() if gopd is not None else None
         ws = _workspace(ctx.ws_bytes, dev)
 
@@ -274,7 +301,8 @@ class TraceFunction(torch.autograd.Function):
                 g_cy.reshape(cy.shape) if need[4] else None,
                 g_c.reshape(c.shape), g_t.reshape(t.shape), g_mu.reshape(mu.shape),
                 g_kappa.reshape(kappa.shape) if asph else None, g_poly.reshape(poly.shape) if asph else None,
-                None, None, g_n.reshape(n_index.shape) if g_n is not None else None, None, None, None, None, None, None)
+                None, None, g_n.reshape(n_index.shape) if g_n is not None else None, None, None, None, None, None, None,
+                None)
 
 
 class SpotRmsFunction(torch.autograd.Function):

@@ -182,7 +182,7 @@ def _rows(a: torch.Tensor, n_lens: int, tail: tuple) -> torch.Tensor:
 
 
 def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_rays=True, mode=None,
-               want_rays=True, kappa=None, poly=None, surf_kind=None, n_index=None, want_opd=False):
+               want_rays=True, kappa=None, poly=None, surf_kind=None, n_index=None, want_opd=False, x_moments=False):
     """Trace rays from the entrance pupil to the image plane through S surface rows.
 
     Same contract as the reference (ray_tracing_lite.py:594-675): inputs broadcast to
@@ -204,6 +204,8 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
       n_index, want_opd   refractive indices [1,1,1,W,S+1] (entry 0 = object space) and a seventh
                   return value: the optical path length per ray, differentiable w.r.t. every lens and launch
                   parameter and w.r.t. n_index (its backward runs the checkpoint kernel);
+      x_moments   also fuse the x-moments of the spot into the trace (for `compute_rms_spot_xy`; compute_rms2d reads
+                  y only, ray_tracing_lite.py:684-701, so by default the kernel does not spend time on them);
       the returned `y` carries the fused spot moments so `compute_rms2d(x, y, ray_ok)` costs no
       second pass over the rays.
     """
@@ -250,12 +252,12 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
         nidx = nidx.reshape(nidx.shape[0] if nidx.dim() == 5 else 1, -1, S + 1).expand(B, W, S + 1).contiguous()
     out = ops.TraceFunction.apply(x_e, y_e, zv, cx2, cy2, c2, t2, mu3, kap, pol, mask_u8, kind_u8, nidx,
                                   bool(allow_backward_rays), mode or ops.get_default_mode(), want_rays, bool(want_opd),
-                                  bool(aggregate), bool(aggregate is True and want_rays))
+                                  bool(aggregate), bool(aggregate is True and want_rays), bool(x_moments))
     xo, yo, cxo, cyo, ok, back, moments, opd, stk = out
     if want_rays:
         # remember which moments belong to these rays (checked by identity + version in compute_rms2d):
         # [B*F, TL_NMOM], lens-major
-        yo._tl_spot = (moments, ok, yo._version, P * W)
+        yo._tl_spot = (moments, ok, yo._version, P * W, bool(x_moments))
         res = (xo, yo, cxo, cyo, ok, back)
         if want_opd:
             res += (opd,)
@@ -381,7 +383,7 @@ def compute_rms_spot_xy(x, y, ray_ok, group=None, n_per_field: Optional[int] = N
     all rays, failed rays at the origin, denominator P*W).  Uses the x- and y-moments fused into the trace
     kernel; differentiable through the same backward kernel."""
     tag = getattr(y, "_tl_spot", None)
-    if tag is not None and tag[1] is ray_ok and tag[2] == y._version:
+    if tag is not None and tag[1] is ray_ok and tag[2] == y._version and tag[4]:      # traced with x_moments=True
         moments, n_local = tag[0], tag[3]
     else:
         moments = ops.SpotMomentsFunction.apply(x, y, ray_ok)
@@ -474,7 +476,8 @@ class RayTracer:
         up, down, vx = (self.vig_fn(fields, v) for v in (specs.vig_up, specs.vig_down, specs.vig_x))
         return apply_vignetting(yp_rel, up, down), apply_vignetting(xp_rel, vx, vx)
 
-    def trace_rays(self, specs, lens, use_vig=True, aggregate=False, xy=None, up_to_stop=False, want_opd=False):
+    def trace_rays(self, specs, lens, use_vig=True, aggregate=False, xy=None, up_to_stop=False, want_opd=False,
+                   x_moments=False):
         a = self.assemble(specs, lens, xy=xy, up_to_stop=up_to_stop, use_vig=use_vig)
         extra = {}
         if "kappa" in a:
@@ -486,6 +489,8 @@ class RayTracer:
                 n = torch.cat((torch.ones_like(n[:, :1, :]), n), dim=1).transpose(1, 2)
                 n = n.reshape(n.shape[0], 1, 1, n.shape[1], -1)
             extra.update(n_index=n, want_opd=True)
+        if x_moments:
+            extra.update(x_moments=True)
         return trace_skew(a['x'], a['y'], a['z'], a['cx'], a['cy'], a['c'], a['t'], a['mu'], a['mask'],
                           aggregate, self.allow_backward_rays, mode=self.arith, **extra)
 
