@@ -224,11 +224,13 @@ int tl_spot_seed(int32_t device, int32_t F, int32_t P, int32_t W,
  *   c, t [B,K], n [B,K+1] (n[.,0] = object space), z [B] (nullable): float; B lenses, one thread each (rows behind a
  *   lens' own stop padded with c = 0, t = 0, n = 1: identity).
  *   g_z [B] (nullable): upstream gradient; then g_c, g_t [B,K] and g_n [B,K+1] are OVERWRITTEN with
- *   d(loss)/d(c, t, n).  fp64 inside; one tiny launch instead of the ~25 (+ ~60 in autograd) of the
- *   elementwise / 2x2-matmul chain.
+ *   d(loss)/d(c, t, n).  One tiny launch instead of the ~25 (+ ~60 in autograd) of the elementwise / 2x2-matmul chain.
+ *   mode (ABI 13): TL_MODE_STRICT -- z is the reference's fp32 value bit for bit (its pairwise product tree of fp32 2x2
+ *   matrices, reduce_abcd :301-318, every operation rounded separately); TL_MODE_FAST -- the product in fp64, rounded
+ *   once.  The gradient is the fp64 adjoint in both modes.
  */
 int tl_pupil_position(int32_t device, int32_t B, int32_t K, const float *c, const float *t, const float *n, float *z,
-                      const float *g_z, float *g_c, float *g_t, float *g_n, void *stream);
+                      const float *g_z, float *g_c, float *g_t, float *g_n, int32_t mode, void *stream);
 
 #ifdef __cplusplus
 }

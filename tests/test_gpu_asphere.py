@@ -370,3 +370,65 @@ def test_lens_batch_with_aspheric_rows_walks_back_over_stored_hits(ta):
     both, first, second = run([0, 1]), run([0]), run([1])
     for g2, ga, gb in zip(both, first, second):
         assert torch.equal(g2[0], ga[0]) and torch.equal(g2[1], gb[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Analytic pins (round 3): geometry and Fermat's principle -- independent of the oracle (tests/analytic_asphere.py)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_stigmatic_conic_focuses_every_ray_and_equalises_the_optical_path(ta, mode):
+    """kappa = -(n1/n2)^2: every ray of the collimated f/2 fan lands within 1e-5 mm of the axis at n2 R / (n2 - n1), and
+    the optical path length from the launch plane is the same for every ray to 1e-5 mm (Fermat).  A sphere of the same
+    radius does neither."""
+    import analytic_asphere as an
+    for pad in (0, 2):
+        args, extra = an.stigmatic_conic(torch.float32, DEV, pad_rows=pad)
+        x, y, cx, cy, ok, back, opd = ta.trace_skew(*args, kappa=extra["kappa"], poly=extra["poly"], surf_kind=extra["surf_kind"],
+                                                    n_index=extra["n_index"], want_opd=True, mode=mode)
+        assert ok.all().item() and x.shape[2] > 3000
+        assert x.abs().max().item() <= 1e-5 and y.abs().max().item() <= 1e-5
+        assert (opd - an.expected_opd(pad_rows=pad)).abs().max().item() <= 1e-5
+        xs, ys, *_, opds = ta.trace_skew(*args, kappa=torch.zeros_like(extra["kappa"]), poly=extra["poly"],
+                                         surf_kind=extra["surf_kind"], n_index=extra["n_index"], want_opd=True, mode=mode)
+        assert xs.abs().max().item() > 0.05 and (opds - an.expected_opd(pad_rows=pad)).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize("pad", [0, 2])
+@pytest.mark.parametrize("algo", ["inverse", "inverse_newton", "checkpoint"])
+def test_spot_size_gradient_changes_sign_at_the_stigmatic_conic_constant(ta, algo, pad):
+    """d sum(x^2 + y^2) / d kappa through the dense per-ray seeds (gx, gy) of the backward kernels: negative below the
+    stigmatic conic constant, positive above it, ~0 at it -- for every backward algorithm (pad = 2: a three-row lens,
+    the row count from which the walk-back runs unrolled over the forward's stored hit points)."""
+    import analytic_asphere as an
+    from torchoptics_amd import ops
+    grads = []
+    _algo(ops, algo)
+    try:
+        for dk in (-0.01, 0.0, +0.01):
+            args, extra = an.stigmatic_conic(torch.float32, DEV, kappa=an.KAPPA_STAR + dk, pad_rows=pad)
+            kap = extra["kappa"].clone().requires_grad_(True)
+            x, y, *_ = ta.trace_skew(*args, kappa=kap, poly=extra["poly"], surf_kind=extra["surf_kind"])
+            assert x.grad_fn.use_inv is (algo != "checkpoint")
+            (x ** 2 + y ** 2).sum().backward()
+            grads.append(kap.grad[-1].item())
+    finally:
+        _algo_reset(ops)
+    # fp64 values from the oracle (tests/test_oracle_asphere.py): the slope of the gradient around kappa*
+    assert grads[0] < 0 < grads[2], grads
+    assert abs(grads[1]) < 1e-3 * abs(grads[2]), grads
+    assert abs(grads[0] + grads[2]) < 0.1 * abs(grads[2]), grads          # nearly antisymmetric: a quadratic minimum
+
+
+@pytest.mark.parametrize("kappa", [-1.0, 0.0, -0.5])
+def test_sag_and_normal_of_conics_against_their_closed_forms(ta, kappa):
+    """Paraboloid (sag = c rho / 2 exactly), sphere, ellipsoid: the z the Newton hit leaves behind (penalty stack
+    z_RELU) and the angle of the surface normal (theta_norm) against the closed forms evaluated in fp64."""
+    import analytic_asphere as an
+    c = 0.08
+    args, extra, h = an.sag_probe(c, kappa, torch.float32, DEV)
+    out = ta.trace_skew(*args, True, True, kappa=extra["kappa"], poly=extra["poly"], surf_kind=[1])
+    st = out[6]
+    got_sag = st["z_RELU"][0].reshape(-1).double().cpu().numpy() - 1.0
+    assert np.abs(got_sag - an.conic_sag(c, kappa, h)).max() < 3e-7            # ~2 ulp of z = 1 + sag
+    got_th = st["theta_norm"][0].reshape(-1).double().cpu().numpy()
+    assert np.abs(got_th[1:] - an.conic_normal_angle(c, kappa, h)[1:]).max() < 2e-6

@@ -237,3 +237,42 @@ def test_batch_without_backward_rays_and_untagged_spot_sizes():
     for b in range(3):
         one = orc.compute_rms2d(want[0][b:b + 1], want[1][b:b + 1], want[4][b:b + 1])
         assert abs(fused[b].item() - one.item()) <= 2e-5 * one.item()      # (the oracle sums in fp32, the kernel in fp64)
+
+
+def test_batch_above_the_grid_row_limit_is_traced_in_lens_chunks():
+    """4 096 lenses x 8 fields x 3 wavelengths = 98 304 (lens, field, wavelength) rows, more than one launch's 65 535:
+    the reference's broadcasting has no such bound (lens_modeling.py:151-386).  trace_skew traces the batch in lens
+    chunks and joins them: per-lens losses and per-lens gradients equal those of the same lenses traced as a small
+    batch in one launch, bit for bit; aggregate='sum' (the real caller's loss) included."""
+    import torchoptics_amd as ta
+    from torchoptics_amd import ray_tracing as rt
+    g, ins, mask = _g11(DEV)
+    B0, S = ins[5].shape[0], ins[5].shape[-1]                      # the three padded lenses of the reference's batch run
+    n_lens, F, W = 4096, 8, 3
+    idx = torch.arange(n_lens, device=DEV) % B0
+    torch.manual_seed(3)
+    jit = 1.0 + 1e-3 * torch.randn(n_lens, 1, 1, 1, 1, device=DEV)              # every lens a little different
+    fields = torch.linspace(0.0, 0.42, F, device=DEV).reshape(1, F, 1, 1)
+    x, y = ins[0][:1, :1, :64, :1].contiguous(), ins[1][:1, :1, :64, :1].contiguous()      # one shared 64-ray fan
+    mu = ins[7][idx].contiguous()                                  # [n_lens,1,1,3,S]; padded rows stay identity rows (mu = 1)
+
+    def run(sel):
+        c = (ins[5][idx] * jit)[sel].clone().requires_grad_(True)
+        t = ins[6][idx][sel].clone().requires_grad_(True)
+        m = mu[sel].clone().requires_grad_(True)
+        out = ta.trace_skew(x, y, ins[2][idx][sel], torch.zeros(1, 1, 1, 1, device=DEV), fields, c, t, m, mask[idx][sel],
+                            aggregate="sum")
+        ld = rt.unsupervised_loss_batch(out, S, 0.2)
+        ld["loss_unsup"].sum().backward()
+        return out, ld, (c.grad, t.grad, m.grad)
+    out, ld, grads = run(slice(0, n_lens))
+    assert out[0].shape == (n_lens, F, 64, W) and ld["rms"].shape == (n_lens,)
+    assert torch.isfinite(ld["loss_unsup"]).all()
+    probe = slice(2730, 2746)                                      # straddles the chunk boundary (65535 // 24 = 2730 lenses)
+    out_s, ld_s, grads_s = run(probe)
+    for k in ("rms", "penalty", "loss_unsup"):
+        assert torch.equal(ld[k][probe], ld_s[k]), k
+    for i in range(6):
+        assert torch.equal(out[i][probe], out_s[i]), i
+    for a, b in zip(grads, grads_s):
+        assert torch.equal(a[probe], b)

@@ -241,7 +241,44 @@ def test_full_chain_cooke_vs_reference_leaf_grads(ta):
     grads = torch.autograd.grad(rms, [leaves[k] for k in ("c", "t", "nd", "v")])
     for k, got in zip(("c", "t", "nd"), grads):
         e32, e64 = rel_l2(got.cpu().numpy(), g["g_" + k]), rel_l2(got.cpu().numpy(), g["g_" + k + "64"])
-        assert min(e32, e64) < 5e-5, f"d/d{k}: vs fp32 {e32:.2e} vs fp64 {e64:.2e}"
+        print(f"full chain d/d{k}: vs fp32 autograd {e32:.2e}, vs fp64 autograd {e64:.2e}")
+        assert e32 < 1e-5, f"d/d{k}: vs fp32 {e32:.2e} vs fp64 {e64:.2e}"      # north_star: <= 1e-5 of PyTorch autograd
+
+
+@pytest.mark.parametrize("case,name,n_rays,wl,epd,hfov", [
+    ("G1_singlet_cfg1", "singlet", (64, 64), ("d",), None, 25.0),
+    ("G2_cooke_16x16", "cooke", (16, 16), ("C", "d", "F"), None, 25.0),
+    ("G4_doublet_32x32", "doublet", (32, 32), ("C", "d", "F"), None, 25.0),
+    ("G4_tessar_32x32", "tessar", (32, 32), ("C", "d", "F"), None, 25.0),
+    ("G5_cooke_failures", "cooke", (32, 32), ("C", "d", "F"), 16.0, 35.0),
+])
+def test_strict_full_chain_reproduces_the_reference_kernel_inputs_and_outputs(ta, case, name, n_rays, wl, epd, hfov):
+    """Strict mode through RayTracer on the GPU: the launch conditions the host chain hands to the kernel are the
+    REFERENCE's fp32 values bit for bit -- z from its pairwise fp32 ABCD tree (tl_pupil_position, mode strict), cy from
+    the correctly rounded sine, c, t, mu, mask as they are; the fan x, y from correctly rounded cos / sin (the
+    reference's own grid is its host libm's, 1 ulp off on a few points) -- and so the per-ray outputs are the IEEE
+    oracle's on the reference's inputs wherever the fan agrees."""
+    import yaml_free_lenses as L
+    from oracle import trace_oracle as orc
+    g = load_golden(case)
+    lens, specs, _ = L.build(name, DEV, epd=epd or L.EPD, hfov_deg=hfov, grad=False)
+    fields = (0.,) if name == "singlet" else (0., 0.707, 1.)
+    tr = ta.RayTracer(mode="circular", n_rays=n_rays, rel_fields=fields, wavelengths=wl, default_device=DEV, arith="strict")
+    a = tr.assemble(specs, lens)
+    for k in ("z", "cy", "cx", "c", "t", "mu", "mask"):
+        assert np.array_equal(a[k].cpu().numpy(), g["in_" + k]), f"{case}: in_{k} is not the reference's value"
+    for k in ("x", "y"):
+        got, want = a[k].cpu().numpy(), g["in_" + k]
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+        near_zero = np.abs(want) < 1e-6                      # cos(pi/2) and friends: tiny values, many ulps, ~1e-8 mm apart
+        # (the fixture machine's fp32 sin / cos is the correctly rounded value on 81-97 % of these grid angles)
+        assert ulp[~near_zero].max() <= 2 and np.abs(got - want)[near_zero].max(initial=0.0) < 1e-6
+        assert (ulp == 0).mean() > 0.75, f"{case}: only {(ulp == 0).mean():.3f} of in_{k} bit-equal"
+    out = ta.trace_skew(a["x"], a["y"], a["z"], a["cx"], a["cy"], a["c"], a["t"], a["mu"], a["mask"], mode="strict")
+    cpu = [a[k].cpu() for k in ("x", "y", "z", "cx", "cy", "c", "t", "mu", "mask")]
+    want = orc.trace_skew(*cpu, ieee_sqrt=True)
+    for nme, u, v in zip(("x", "y", "cx", "cy", "ok", "back"), out, want):
+        assert torch.equal(u.cpu(), v), f"{case}: {nme} differs from the IEEE oracle on the same inputs"
 
 
 def test_cfg2_full_size_scalars(ta):
@@ -261,9 +298,12 @@ def test_cfg2_full_size_scalars(ta):
     grads = torch.autograd.grad(rms, [leaves[k] for k in ("c", "t", "nd")])
     for k, got in zip(("c", "t", "nd"), grads):
         e32, e64 = rel_l2(got.cpu().numpy(), g["g_" + k]), rel_l2(got.cpu().numpy(), g["g_" + k + "64"])
-        print(f"cfg2 d/d{k}: vs fp32 autograd {e32:.2e}, vs fp64 autograd {e64:.2e}, "
-              f"fp32-vs-fp64 of the reference {rel_l2(g['g_' + k], g['g_' + k + '64']):.2e}")
-        assert e64 < 5e-5, f"d/d{k} vs fp64: {e64:.2e}"
+        ref = rel_l2(g['g_' + k], g['g_' + k + '64'])
+        print(f"cfg2 d/d{k}: vs fp32 autograd {e32:.2e}, vs fp64 autograd {e64:.2e}, fp32-vs-fp64 of the reference {ref:.2e}")
+        # <= 1e-5 of the reference's fp32 autograd -- or at least as close to fp64 as the reference's own fp32 run is
+        # (its 1024 x 1024 grid comes from its host libm's cos / sin, ours from correctly rounded ones: two fp32
+        # evaluations of the same fan)
+        assert e32 < 1e-5 or e64 <= ref, f"d/d{k}: vs fp32 {e32:.2e}, vs fp64 {e64:.2e} (reference fp32 itself {ref:.2e})"
 
 
 @pytest.mark.parametrize("fused", [True, False])

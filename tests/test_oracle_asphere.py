@@ -139,3 +139,57 @@ def test_penalty_and_opd_gradients_on_aspheric_rows_match_finite_differences():
             tens[idx] = base
         fd = (lp - lm_) / (2 * h)
         assert abs(tens.grad[idx].item() - fd) <= 5e-5 * abs(fd) + 1e-9, (idx, tens.grad[idx].item(), fd)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Analytic pins (round 3): geometry and Fermat's principle, independent of this oracle and of the kernels
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol_xy,tol_opd", [(torch.float64, 1e-11, 1e-11), (torch.float32, 1e-5, 1e-5)])
+def test_stigmatic_conic_focuses_every_ray_and_equalises_the_optical_path(dtype, tol_xy, tol_opd):
+    import analytic_asphere as an
+    for pad in (0, 2):
+        args, extra = an.stigmatic_conic(dtype, pad_rows=pad)
+        o = orc.trace_skew_general(*args, extra["kappa"], extra["poly"], extra["surf_kind"], n_index=extra["n_index"],
+                                   ieee_sqrt=(dtype == torch.float32))
+        x, y, ok, opd = o[0], o[1], o[4], o[6]
+        assert ok.all() and x.shape[2] > 3000
+        assert x.abs().max().item() <= tol_xy and y.abs().max().item() <= tol_xy
+        assert (opd - an.expected_opd(pad_rows=pad)).abs().max().item() <= tol_opd      # Fermat: one optical path for every ray
+        # ... and a SPHERE of the same radius does neither (the case is not vacuous)
+        o = orc.trace_skew_general(*args, torch.zeros_like(extra["kappa"]), extra["poly"], extra["surf_kind"], n_index=extra["n_index"])
+        assert o[0].abs().max().item() > 0.05 and (o[6] - an.expected_opd(pad_rows=pad)).abs().max().item() > 1e-3
+
+
+def test_spot_size_gradient_changes_sign_at_the_stigmatic_conic_constant():
+    import analytic_asphere as an
+    grads = []
+    for dk in (-0.01, 0.0, +0.01):
+        args, extra = an.stigmatic_conic(torch.float64, kappa=an.KAPPA_STAR + dk, pad_rows=2)
+        kap = extra["kappa"].clone().requires_grad_(True)
+        o = orc.trace_skew_general(*args, kap, extra["poly"], extra["surf_kind"])
+        (o[0] ** 2 + o[1] ** 2).sum().backward()
+        grads.append(kap.grad[-1].item())
+    assert grads[0] < 0 < grads[2] and abs(grads[1]) < 1e-6 * abs(grads[2])
+
+
+@pytest.mark.parametrize("kappa", [-1.0, 0.0, -0.5])
+def test_sag_and_slope_of_conics_against_their_closed_forms(kappa):
+    """Paraboloid (kappa = -1): sag = c rho / 2 exactly, d sag / d rho = c / 2; sphere and an ellipsoid likewise against
+    the textbook conic."""
+    import analytic_asphere as an
+    c = 0.08
+    rho = torch.linspace(0, 16, 129, dtype=torch.float64)
+    sag, dsag, bad = orc._sag_terms(torch.tensor(c, dtype=torch.float64), torch.tensor(kappa, dtype=torch.float64),
+                                    torch.zeros(4, dtype=torch.float64), rho)
+    assert not bad.any()
+    assert np.abs(sag.numpy() - an.conic_sag(c, kappa, np.sqrt(rho.numpy()))).max() < 1e-14
+    want_dsag = c / (2 * np.sqrt(1 - (1 + kappa) * c * c * rho.numpy()))
+    assert np.abs(dsag.numpy() - want_dsag).max() < 1e-14
+    if kappa == -1.0:
+        assert np.abs(dsag.numpy() - c / 2).max() < 1e-16
+    # the same through the trace: z_RELU returns the sag at the Newton hit, theta_norm the normal's angle
+    args, extra, h = an.sag_probe(c, kappa, torch.float64)
+    o = orc.trace_skew_general(*args, extra["kappa"], extra["poly"], [1], aggregate=True)
+    st = o[7]
+    assert np.abs(st["z_RELU"][0].reshape(-1).numpy() - (an.conic_sag(c, kappa, h) + 1.0)).max() < 1e-12
+    assert np.abs(st["theta_norm"][0].reshape(-1).numpy()[1:] - an.conic_normal_angle(c, kappa, h)[1:]).max() < 1e-7

@@ -52,7 +52,7 @@ _SIGNATURES = {
     "tl_spot_moments": (C.c_int, [C.c_int32] * 4 + [_VP] * 3 + [C.c_int64] * 3 + [_VP, _VP, C.c_size_t, _VP]),
     "tl_spot_rms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, _VP, _VP, _VP, _VP]),
     "tl_spot_seed": (C.c_int, [C.c_int32] * 4 + [_VP] * 3 + [C.c_int64] * 3 + [_VP] * 4),
-    "tl_pupil_position": (C.c_int, [C.c_int32] * 3 + [_VP] * 9),
+    "tl_pupil_position": (C.c_int, [C.c_int32] * 3 + [_VP] * 8 + [C.c_int32, _VP]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -296,11 +296,44 @@ __global__ __launch_bounds__(kBlock) void spot_seed_kernel(int P, int W, const f
 // Replaces ~25 tiny elementwise / 2x2-matmul launches of the host chain and ~60 of its autograd backward.
 // A batch of B lenses: c, t [B,K], n [B,K+1], z, g_z [B]; rows behind a lens' own stop are padded (c = 0, t = 0,
 // n = 1): identity matrices.
+// strict: the VALUE of z is the reference's fp32 arithmetic, operation for operation -- 2x2 matrices of fp32 entries
+// [[1 + P t, r t], [P, r]], multiplied pairwise in a halving tree (reduce_abcd, ray_tracing_lite.py:301-318: rows
+// (1,0), (3,2) ... then the products again, an odd one carried), every product and sum rounded separately (the
+// reference's tiny batched matmul does not fuse; checked bit for bit against the z of fixtures G1-G11 on the Cooke
+// triplet, the doublet and the Tessar).  The gradient stays the fp64 adjoint below: the derivative of the exact
+// function, which the derivative of the rounded one equals to rounding.
+__device__ float pupil_position_fp32_tree(int K, const float *__restrict__ c, const float *__restrict__ t,
+                                          const float *__restrict__ n)
+{
+    float M[TL_MAX_SURFACES][4];
+    for (int k = 0; k < K; ++k) {
+        const float r = __fdiv_rn(n[k], n[k + 1]);
+        const float P = __fmul_rn(c[k], __fsub_rn(r, 1.0f));
+        M[k][0] = __fadd_rn(1.0f, __fmul_rn(P, t[k])); M[k][1] = __fmul_rn(r, t[k]); M[k][2] = P; M[k][3] = r;
+    }
+    int cnt = K;
+    while (cnt > 1) {
+        const int even = cnt - (cnt & 1);
+        for (int i = 0; i < even; i += 2) {          // out[i/2] = M[i+1] @ M[i]
+            const float a0 = M[i + 1][0], a1 = M[i + 1][1], a2 = M[i + 1][2], a3 = M[i + 1][3];
+            const float b0 = M[i][0], b1 = M[i][1], b2 = M[i][2], b3 = M[i][3];
+            float *o = M[i >> 1];
+            o[0] = __fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b2));
+            o[1] = __fadd_rn(__fmul_rn(a0, b1), __fmul_rn(a1, b3));
+            o[2] = __fadd_rn(__fmul_rn(a2, b0), __fmul_rn(a3, b2));
+            o[3] = __fadd_rn(__fmul_rn(a2, b1), __fmul_rn(a3, b3));
+        }
+        if (cnt & 1) { for (int j = 0; j < 4; ++j) M[even >> 1][j] = M[cnt - 1][j]; }
+        cnt = (even >> 1) + (cnt & 1);
+    }
+    return __fdiv_rn(M[0][1], M[0][0]);
+}
+
 __global__ __launch_bounds__(64) void pupil_position_kernel(int B, int K, const float *__restrict__ c,
                                                             const float *__restrict__ t, const float *__restrict__ n,
                                                             float *__restrict__ z, const float *__restrict__ g_z,
                                                             float *__restrict__ g_c, float *__restrict__ g_t,
-                                                            float *__restrict__ g_n)
+                                                            float *__restrict__ g_n, int strict)
 {
     const int lens = blockIdx.x * 64 + threadIdx.x;
     if (lens >= B) return;
@@ -316,7 +349,7 @@ __global__ __launch_bounds__(64) void pupil_position_kernel(int B, int K, const 
         const double na = m00 * a + m01 * cc, nb = m00 * b + m01 * d, nc = m10 * a + m11 * cc, nd = m10 * b + m11 * d;
         a = na; b = nb; cc = nc; d = nd;
     }
-    if (z) z[0] = (float)(b / a);
+    if (z) z[0] = strict ? pupil_position_fp32_tree(K, c, t, n) : (float)(b / a);
     if (!g_z) return;
     // reverse mode: G = d z / d M_full, carried down as G_k = L_k^T G with L_k = M_{K-1} ... M_{k+1}
     const double gz = (double)g_z[0];
@@ -570,14 +603,16 @@ int tl_spot_seed(int32_t device, int32_t F, int32_t P, int32_t W, const float *x
 }
 
 int tl_pupil_position(int32_t device, int32_t B, int32_t K, const float *c, const float *t, const float *n, float *z,
-                      const float *g_z, float *g_c, float *g_t, float *g_n, void *stream)
+                      const float *g_z, float *g_c, float *g_t, float *g_n, int32_t mode, void *stream)
 {
+    if (mode != TL_MODE_STRICT && mode != TL_MODE_FAST) return fail(TL_EINVAL, "unknown mode");
     if (B < 1 || K < 1 || K > TL_MAX_SURFACES || !c || !t || !n) return fail(TL_EINVAL, "tl_pupil_position: bad argument");
     if (!z && !g_z) return fail(TL_EINVAL, "tl_pupil_position: neither z nor g_z given");
     if (g_z && (!g_c || !g_t || !g_n)) return fail(TL_EINVAL, "tl_pupil_position: g_z needs g_c, g_t and g_n");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-    hipLaunchKernelGGL(pupil_position_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, K, c, t, n, z, g_z, g_c, g_t, g_n);
+    hipLaunchKernelGGL(pupil_position_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, K, c, t, n, z, g_z, g_c, g_t, g_n,
+                       mode == TL_MODE_STRICT ? 1 : 0);
     const int herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "pupil_position_kernel launch");
     return TL_OK;

@@ -28,7 +28,10 @@ _CONST = {}
 
 
 def const_tensor(values, dtype, device, shape=None):
-    key = (tuple(np.ravel(values).tolist()), dtype, str(device), shape)
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (tuple(np.ravel(values).tolist()), dtype, device, shape)
     t = _CONST.get(key)
     if t is None:
         t = torch.tensor(values, dtype=dtype)

@@ -78,7 +78,7 @@ def compute_ray_aiming_error(specs, lens, rel_fields, vig_fn=None, n_ray_aiming_
     return ys / rs - y
 
 
-def compute_psf(x, y, n_bins=(21, 21), increment=None, y_target=None, weights=None):
+def compute_psf(x, y, n_bins=(21, 21), increment=None, y_target=None, weights=None, y_extent="reference"):
     """Soft-histogram PSF of a ray fan on a per-field pixel grid (the reference's TensorFlow
     `compute_psf`, ray_tracing.py:206-270; unreachable in its PyTorch port, PARITY UNPINNED).
 
@@ -89,6 +89,12 @@ def compute_psf(x, y, n_bins=(21, 21), increment=None, y_target=None, weights=No
     x >= 0 half of the grid is evaluated and mirrored (the pupil is sampled symmetrically in x), and each
     channel's kernel is normalised to unit sum.
     `weights` (extension; same shape as x): per-ray weights, e.g. ray_ok as float to leave failed rays out.
+    `y_extent` (increment=None only): "reference" (default) sizes the grid exactly as the reference text does --
+    y_size = 2 max(y_max - y_target, y_target - y_min) with y_min, y_max taken AFTER y was centred on y_target
+    (ray_tracing.py:220-231), i.e. y_target is subtracted twice (sic): for an off-axis field (y_target = 3 mm, spot
+    +-0.06 mm) the grid spans 6.12 mm, not 0.12 mm, and the spot fills one pixel.  Kept because this function stands in
+    for that text number for number; "centred" is the evident intent, y_size = 2 max(y_max, -y_min) of the centred y
+    (a deviation from the reference, off by default; `psf_from_trace`, an extension, uses it).
 
     Returns (x_size, y_size, y_target, kernels [n_grids, n_channels, n_y_bins, n_x_bins],
     accounted_ray_proportion [n_grids]).
@@ -112,7 +118,12 @@ def compute_psf(x, y, n_bins=(21, 21), increment=None, y_target=None, weights=No
         flat_y = y.reshape(n_grids, -1)
         y_c_min, y_c_max = flat_y.min(dim=1).values, flat_y.max(dim=1).values      # y is centred already
         x_size = x.reshape(n_grids, -1).max(dim=1).values
-        y_size = 2 * torch.maximum(y_c_max, -y_c_min)
+        if y_extent == "reference":
+            y_size = 2 * torch.maximum(y_c_max - y_target, y_target - y_c_min)     # (sic) ray_tracing.py:231
+        elif y_extent == "centred":
+            y_size = 2 * torch.maximum(y_c_max, -y_c_min)
+        else:
+            raise ValueError("y_extent must be 'reference' or 'centred'")
         x_incr = x_size / n_x_bins
         y_incr = y_size / n_y_bins
     rng = lambda n: torch.arange(n, dtype=x.dtype, device=x.device)                 # noqa: E731
@@ -138,10 +149,11 @@ def compute_psf(x, y, n_bins=(21, 21), increment=None, y_target=None, weights=No
     return x_size, y_size, y_target, kernels, accounted.to(x.dtype).mean(dim=(-1, -2))
 
 
-def psf_from_trace(x, y, ray_ok=None, n_bins=(21, 21), increment=None, y_target=None):
+def psf_from_trace(x, y, ray_ok=None, n_bins=(21, 21), increment=None, y_target=None, y_extent="centred"):
     """compute_psf on the outputs of RayTracer.trace_rays / trace_skew ([1, F, P, W]; their memory is already
     [F, W, P], so the permutation below is free).  With `ray_ok` failed rays are left out of the histogram and of
-    the default y_target (the reference counts them as rays at the origin)."""
+    the default y_target (the reference counts them as rays at the origin).  An extension with no counterpart in the
+    reference: the automatic grid is sized on the centred spot (`y_extent="centred"`, see compute_psf)."""
     xt, yt = x.permute(0, 1, 3, 2), y.permute(0, 1, 3, 2)
     w = None
     if ray_ok is not None:
@@ -149,4 +161,4 @@ def psf_from_trace(x, y, ray_ok=None, n_bins=(21, 21), increment=None, y_target=
         if y_target is None:
             n_g = yt.shape[0] * yt.shape[1]
             y_target = (yt * w).reshape(n_g, -1).sum(dim=1) / w.reshape(n_g, -1).sum(dim=1).clamp_min(1)
-    return compute_psf(xt, yt, n_bins=n_bins, increment=increment, y_target=y_target, weights=w)
+    return compute_psf(xt, yt, n_bins=n_bins, increment=increment, y_target=y_target, weights=w, y_extent=y_extent)

@@ -383,10 +383,12 @@ class SpotMomentsFunction(torch.autograd.Function):
 
 class PupilPositionFunction(torch.autograd.Function):
     """z [B] = paraxial entrance-pupil position from the rows in front of the stop: c, t [B,K], n [B,K+1]
-    (tl_pupil_position: one tiny kernel forward, one backward, one thread per lens, fp64 inside)."""
+    (tl_pupil_position: one tiny kernel forward, one backward, one thread per lens; mode 'strict': the value is the
+    reference's fp32 product tree bit for bit, 'fast': fp64 inside, rounded once; default ops.get_default_mode())."""
 
     @staticmethod
-    def forward(ctx, c, t, n):
+    def forward(ctx, c, t, n, mode=None):
+        ctx.mode = _MODES[mode or _default_mode]
         for name, ten in (("c", c), ("t", t), ("n", n)):
             _require_device(ten, name)
         B, K = c.shape
@@ -396,7 +398,7 @@ class PupilPositionFunction(torch.autograd.Function):
         z = torch.empty(B, dtype=torch.float32, device=c.device)
         with _on_device(c.device):
             rc = _lib.lib().tl_pupil_position(c.device.index, B, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), _lib.ptr(z),
-                                              None, None, None, None, _stream_ptr(c.device))
+                                              None, None, None, None, ctx.mode, _stream_ptr(c.device))
         _lib.check(rc, "tl_pupil_position")
         ctx.save_for_backward(c, t, n)
         return z
@@ -409,7 +411,7 @@ class PupilPositionFunction(torch.autograd.Function):
         g_c, g_t, g_n = torch.empty_like(c), torch.empty_like(t), torch.empty_like(n)
         with _on_device(c.device):
             rc = _lib.lib().tl_pupil_position(c.device.index, B, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), None,
-                                              _lib.ptr(g_z), _lib.ptr(g_c), _lib.ptr(g_t), _lib.ptr(g_n),
+                                              _lib.ptr(g_z), _lib.ptr(g_c), _lib.ptr(g_t), _lib.ptr(g_n), ctx.mode,
                                               _stream_ptr(c.device))
         _lib.check(rc, "tl_pupil_position (backward)")
-        return g_c, g_t, g_n
+        return g_c, g_t, g_n, None

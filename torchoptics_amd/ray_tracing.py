@@ -35,19 +35,34 @@ def tee(tensor=None, device="cuda"):
     return x, y
 
 
+def _cos_sin(th):
+    """cos and sin of the fp32 grid angles.  On the GPU: evaluated in fp64 and rounded once, i.e. the correctly rounded
+    fp32 values -- what the reference's host libm gives wherever it rounds correctly -- rather than the device's fp32
+    cos / sin (1-2 ulp), so that the fan a GPU run traces is the reference's fan to the last bit on almost every ray."""
+    if th.is_cuda and th.dtype == torch.float32:
+        t64 = th.double()
+        return torch.cos(t64).float(), torch.sin(t64).float()
+    return torch.cos(th), torch.sin(th)
+
+
 def circle(tensor, n_r, n_theta, default_device="cuda"):
     """Polar grid: radii linspace(0,1,n_r) and angles linspace(0,2pi,n_theta), both without the
-    end point -- so n_theta coincident rays at r=0 and none at r=1 (reference quirk B7, kept)."""
+    end point -- so n_theta coincident rays at r=0 and none at r=1 (reference quirk B7, kept).
+    Small grids are cached per device and returned as shared tensors: treat them as read-only."""
     # the grid is a constant of (n_r, n_theta, device): small ones are kept, so that a step that builds its fan inside
     # a captured HIP graph does no host-to-device copy (and an eager loop saves six launches per step)
-    key = (n_r, n_theta, str(default_device))
+    dev = torch.device(default_device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())       # "cuda" means another device after set_device
+    key = (n_r, n_theta, dev)
     hit = _CIRCLE.get(key)
     if hit is not None:
-        return hit
+        return hit          # shared, READ-ONLY tensors (the reference returns fresh ones: clone before editing in place)
     r = torch.from_numpy(np.linspace(0, 1.0, n_r, endpoint=False, dtype=np.float32)).to(default_device)
     th = torch.from_numpy(np.linspace(0, 2 * np.pi, n_theta, endpoint=False, dtype=np.float32)).to(default_device)
-    x = r[None, :, None] * torch.cos(th)[None, None, :]
-    y = r[None, :, None] * torch.sin(th)[None, None, :]
+    cos_th, sin_th = _cos_sin(th)
+    x = r[None, :, None] * cos_th[None, None, :]
+    y = r[None, :, None] * sin_th[None, None, :]
     out = x.reshape(-1, 1, n_r * n_theta, 1), y.reshape(-1, 1, n_r * n_theta, 1)
     if n_r * n_theta <= (1 << 16) and len(_CIRCLE) < 16:
         _CIRCLE[key] = out
@@ -63,8 +78,9 @@ def circle_index_range(n_r, n_theta, start, stop, default_device="cuda"):
     r_all = torch.from_numpy(np.linspace(0, 1.0, n_r, endpoint=False, dtype=np.float32)).to(default_device)
     th_all = torch.from_numpy(np.linspace(0, 2 * np.pi, n_theta, endpoint=False, dtype=np.float32)).to(default_device)
     idx = torch.arange(start, stop, device=default_device)
-    r, th = r_all[idx // n_theta], th_all[idx % n_theta]
-    return (r * torch.cos(th)).reshape(1, 1, -1, 1), (r * torch.sin(th)).reshape(1, 1, -1, 1)
+    cos_all, sin_all = _cos_sin(th_all)
+    r, k = r_all[idx // n_theta], idx % n_theta
+    return (r * cos_all[k]).reshape(1, 1, -1, 1), (r * sin_all[k]).reshape(1, 1, -1, 1)
 
 
 def circle_pseudo_random(tensor, n_r, n_theta):
@@ -210,6 +226,15 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
       second pass over the rays.
     """
     B = max(a.shape[0] for a in (x, y, z, cx, cy, c, t, mu, mask) if torch.is_tensor(a) and a.dim() >= 4)
+    if B > 1:
+        # one launch takes at most _MAX_GRID_ROWS (lens, field, wavelength) rows (the grid's y dimension); the
+        # reference's broadcasting has no such bound (4 096 lenses x 8 fields x 3 wavelengths = 98 304 rows): trace a
+        # larger batch in lens chunks and join the results
+        rows_per_lens = (max(a.shape[1] for a in (x, y, cx, cy)) * max(x.shape[3], y.shape[3], mu.shape[3]))
+        if B * rows_per_lens > _MAX_GRID_ROWS:
+            return _trace_skew_in_lens_chunks(max(1, _MAX_GRID_ROWS // rows_per_lens), B, x, y, z, cx, cy, c, t, mu, mask,
+                                              aggregate, allow_backward_rays, mode, want_rays, kappa, poly, surf_kind,
+                                              n_index, want_opd, x_moments)
     x, y, z, cx, cy = (_as_f32(a, n) for a, n in ((x, 'x'), (y, 'y'), (z, 'z'), (cx, 'cx'), (cy, 'cy')))
     c, t, mu = _as_f32(c, 'c'), _as_f32(t, 't'), _as_f32(mu, 'mu')
     for a, n in ((x, 'x'), (y, 'y'), (cx, 'cx'), (cy, 'cy'), (z, 'z')):
@@ -265,6 +290,43 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
             res += (PenaltyStacks(stk if aggregate is True else None, moments, B),)
         return res
     return moments
+
+
+_MAX_GRID_ROWS = 65535          # gridDim.y limit = B * F * W of one launch (tl_trace.h: tl_problem.B)
+
+
+def _trace_skew_in_lens_chunks(nb, B, x, y, z, cx, cy, c, t, mu, mask, aggregate, allow_backward_rays, mode, want_rays,
+                               kappa, poly, surf_kind, n_index, want_opd, x_moments):
+    """trace_skew of a lens batch too large for one launch: `nb` lenses at a time, results joined along the lens axis
+    (the per-ray outputs are copied once more -- such batches are many small fans, not few large ones)."""
+    def part(a, b0, b1, lens_dims):
+        # an argument that carries the lens axis (dim 0 of size B) is sliced, one shared by all lenses is passed as is
+        if not torch.is_tensor(a) or a.dim() not in lens_dims or a.shape[0] != B:
+            return a
+        return a[b0:b1]
+    outs = []
+    for b0 in range(0, B, nb):
+        b1 = min(B, b0 + nb)
+        args = [part(a, b0, b1, (4, 5)) for a in (x, y, z, cx, cy, c, t, mu, mask)]
+        kw = dict(kappa=part(kappa, b0, b1, (2,)), poly=part(poly, b0, b1, (3,)),
+                  surf_kind=part(surf_kind, b0, b1, (2,)) if torch.is_tensor(surf_kind) else surf_kind,
+                  n_index=part(n_index, b0, b1, (5,)))
+        outs.append(trace_skew(*args, aggregate, allow_backward_rays, mode=mode, want_rays=want_rays, want_opd=want_opd,
+                               x_moments=x_moments, **kw))
+    if not want_rays:
+        return torch.cat(outs, dim=0)                      # moments [B*F, TL_NMOM], lens-major
+    n_ray = 6 + (1 if want_opd else 0)
+    res = [torch.cat([o[i] for o in outs], dim=0) for i in range(n_ray)]
+    moments = torch.cat([o[1]._tl_spot[0] for o in outs], dim=0)
+    res[1]._tl_spot = (moments, res[4], res[1]._version, outs[0][1]._tl_spot[3], bool(x_moments))
+    if aggregate:
+        stk = None
+        if aggregate is True:
+            keys = ('z_RELU', 'theta_norm', 'theta_prime_norm')
+            stk = torch.stack([torch.stack([torch.cat([o[n_ray][k][j] for o in outs], dim=0)
+                                            for j in range(len(outs[0][n_ray][k]))]) for k in keys])
+        res.append(PenaltyStacks(stk, moments, B))
+    return tuple(res)
 
 
 class PenaltyStacks(dict):
@@ -449,7 +511,8 @@ class RayTracer:
         n = lens.get_refractive_indices(self.wavelengths)                 # [1, S, W]
         n = torch.cat((torch.ones_like(n[:, :1, :]), n), dim=1).transpose(1, 2)
         n = n.reshape(n.shape[0], 1, 1, n.shape[1], -1)                   # [1,1,1,W,S+1]
-        z = compute_pupil_position(lens).reshape(-1, 1, 1, 1)
+        strict = (self.arith or ops.get_default_mode()) == "strict"
+        z = compute_pupil_position(lens, self.arith).reshape(-1, 1, 1, 1)
         xp_rel, yp_rel = self.pupil_span(z) if xy is None else xy
         if use_vig and self.vig_fn is not None and self.mode != 'chief':
             yp_rel, xp_rel = self._vignette(specs, yp_rel.to(dev), xp_rel.to(dev))
@@ -458,7 +521,10 @@ class RayTracer:
             xp_rel, yp_rel = (torch.clamp(v, -2, 2).to(dev).detach() for v in aim(xp_rel, yp_rel))
         from .lens_modeling import const_tensor
         fields = const_tensor(list(self.rel_fields), torch.float32, dev)
-        cy = torch.sin((specs.hfov[:, None] * fields[None, :])[..., None, None])
+        ang = (specs.hfov[:, None] * fields[None, :])[..., None, None]
+        # strict: the correctly rounded fp32 sine (evaluated in fp64, rounded once) -- the reference's value on every CPU
+        # whose libm rounds correctly there, and the fixtures' bit for bit; fast: the device's fp32 sine
+        cy = torch.sin(ang.double()).to(ang.dtype) if (strict and ang.is_cuda and ang.dtype == torch.float32) else torch.sin(ang)
         cx = const_tensor([0.0], torch.float32, dev, (1, 1, 1, 1))
         out = dict(
             x=scale_to_epd(xp_rel.to(dev), specs.epd), y=scale_to_epd(yp_rel.to(dev), specs.epd), z=z, cx=cx, cy=cy,
