@@ -501,7 +501,7 @@ def main():
                        "parallelism": f"pupil-sharded dp{world}",
                        "collectives": "none" if group is None else ("rccl" if a.backend == "nccl" else a.backend),
                        "collective_shape": None if group is None else tl_dist.get_collective(),
-                       "rms": float(rms.item()), "hip_graph": bool(a.graph)},
+                       "rms": float(rms.item()), "hip_graph": bool(a.graph), "host_chain": ops.host_chain()},
             "roofline": roofline, "roofline_valu": roofline_valu, "kernels": kernels,
             "step_hbm_GBs": job.rays_total * step_bpr / (head["ms_per_step"] * 1e6),
             "grad_rel_err_vs_pytorch_autograd": grad_check,

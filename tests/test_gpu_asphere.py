@@ -15,6 +15,11 @@ from conftest import load_golden, rel_l2
 from test_oracle_asphere import asphere_params
 
 pytestmark = pytest.mark.gpu
+
+
+def _used_walk_back(t):
+    from torchoptics_amd import ops
+    return ops.used_walk_back(t)
 DEV = "cuda:0"
 IN = ("in_x", "in_y", "in_z", "in_cx", "in_cy", "in_c", "in_t", "in_mu")
 
@@ -79,7 +84,7 @@ def test_newton_rows_everywhere_give_the_spherical_gradients(ta, algo):
             extra = {} if tag == "sph" else dict(kappa=torch.zeros(S, device=DEV), poly=torch.zeros(S, 4, device=DEV),
                                                  surf_kind=kind)
             x, y, cx, cy, ok, back = ta.trace_skew(*dev[:5], *lv, mask.to(DEV), **extra)
-            assert x.grad_fn.use_inv is (algo != "checkpoint")
+            assert _used_walk_back(x) is (algo != "checkpoint")
             ta.compute_rms2d(x, y, ok).backward()
             grads[tag] = [q.grad.cpu().numpy() for q in lv]
     finally:
@@ -136,7 +141,7 @@ def test_asphere_gradients_match_oracle_autograd(ta, algo, mode):
     try:
         x, y, cx, cy, ok, back = ta.trace_skew(ins[0].to(DEV), ins[1].to(DEV), lv[0], ins[3].to(DEV), lv[1], lv[2],
                                                lv[3], lv[4], mask.to(DEV), kappa=lv[5], poly=lv[6], mode=mode)
-        assert x.grad_fn.use_inv is (algo != "checkpoint")
+        assert _used_walk_back(x) is (algo != "checkpoint")
         ta.compute_rms2d(x, y, ok).backward()
     finally:
         _algo_reset(ops)
@@ -231,7 +236,7 @@ def test_gradient_through_the_optical_path_length(ta, aspheric, mode):
     extra = dict(kappa=lv[6], poly=lv[7]) if aspheric else {}
     out = ta.trace_skew(ins[0].to(DEV), ins[1].to(DEV), lv[0], ins[3].to(DEV), lv[1], lv[2], lv[3], lv[4],
                         mask.to(DEV), n_index=lv[5], want_opd=True, mode=mode, **extra)
-    assert out[0].grad_fn.use_inv is False            # the walk-back kernel does not carry the OPD gradient
+    assert _used_walk_back(out[0]) is False            # the walk-back kernel does not carry the OPD gradient
     ((out[6] * wts.to(DEV)).sum() + ta.compute_rms2d(out[0], out[1], out[4])).backward()
     tol = 2e-5 if mode == "strict" else 2e-4
     for nme, q, g32, g64 in zip(names, lv, res["f32"], res["f64"]):
@@ -363,7 +368,7 @@ def test_lens_batch_with_aspheric_rows_walks_back_over_stored_hits(ta):
         lv = [rep(ins[i]).to(DEV).requires_grad_(True) for i in (5, 6, 7)]
         k, p_ = kap[sel].to(DEV).requires_grad_(True), pol[sel].to(DEV).requires_grad_(True)
         o = ta.trace_skew(*[a.to(DEV) for a in ins[:5]], *lv, mask.to(DEV), kappa=k, poly=p_)
-        assert o[0].grad_fn.use_inv
+        assert _used_walk_back(o[0])
         from torchoptics_amd import ray_tracing as rt
         rt.compute_rms2d_batch(o[0], o[1], o[4]).sum().backward()
         return [q.grad.cpu() for q in (*lv, k, p_)]
@@ -408,7 +413,7 @@ def test_spot_size_gradient_changes_sign_at_the_stigmatic_conic_constant(ta, alg
             args, extra = an.stigmatic_conic(torch.float32, DEV, kappa=an.KAPPA_STAR + dk, pad_rows=pad)
             kap = extra["kappa"].clone().requires_grad_(True)
             x, y, *_ = ta.trace_skew(*args, kappa=kap, poly=extra["poly"], surf_kind=extra["surf_kind"])
-            assert x.grad_fn.use_inv is (algo != "checkpoint")
+            assert _used_walk_back(x) is (algo != "checkpoint")
             (x ** 2 + y ** 2).sum().backward()
             grads.append(kap.grad[-1].item())
     finally:
@@ -431,4 +436,8 @@ def test_sag_and_normal_of_conics_against_their_closed_forms(ta, kappa):
     got_sag = st["z_RELU"][0].reshape(-1).double().cpu().numpy() - 1.0
     assert np.abs(got_sag - an.conic_sag(c, kappa, h)).max() < 3e-7            # ~2 ulp of z = 1 + sag
     got_th = st["theta_norm"][0].reshape(-1).double().cpu().numpy()
-    assert np.abs(got_th[1:] - an.conic_normal_angle(c, kappa, h)[1:]).max() < 2e-6
+    want_th = an.conic_normal_angle(c, kappa, h)
+    # acos near cos = 1: one fp32 ulp of the cosine (6e-8) moves the angle by 6e-8 / sin(theta) -- 3e-5 of a quadrant at
+    # the first height of this fan, 2e-7 at its edge
+    tol = 2e-6 + 1.5e-7 / np.maximum(want_th * (np.pi / 2), 1e-6) / (np.pi / 2)
+    assert (np.abs(got_th - want_th)[1:] <= tol[1:]).all()

@@ -61,7 +61,7 @@ def test_pupil_position_feeds_trace_rays_and_the_adam_step():
         c, t = leaves["c"].detach().clone().requires_grad_(True), leaves["t"].detach().clone().requires_grad_(True)
         lens = ta.Lens(lens0.structure, c, t, leaves["nd"].detach(), leaves["v"].detach())
         if tag == "chain":
-            def chain(lz):
+            def chain(lz, mode=None):
                 front = lz.up_to_stop()
                 m = paraxial.reduce_abcd(paraxial.interface_propagation_abcd(front.c, front.t,
                                                                             paraxial._with_air_in_front(front.nd)))
@@ -92,7 +92,7 @@ def test_pupil_position_c_abi_edges():
         g = [torch.empty(K, device=DEV), torch.empty(K, device=DEV), torch.empty(K + 1, device=DEV)]
         gz = torch.ones(1, device=DEV)
         assert lib.tl_pupil_position(0, 1, K, _lib.ptr(c), _lib.ptr(t), _lib.ptr(n), _lib.ptr(z), _lib.ptr(gz),
-                                     *[_lib.ptr(q) for q in g], st) == 0
+                                     *[_lib.ptr(q) for q in g], _lib.MODE_FAST, st) == 0
         cd, td, nd = (q.double().cpu().requires_grad_(True) for q in (c, t, n))
         m = torch.eye(2, dtype=torch.float64)
         for k in range(K):
@@ -109,11 +109,11 @@ def test_pupil_position_c_abi_edges():
     z = torch.empty(1, device=DEV)
     bad = [(0, c, c, n, z), (_lib.TL_MAX_SURFACES + 1, c, c, n, z), (4, None, c, n, z), (4, c, c, n, None)]
     for K, a, b, nn, zz_ in bad:
-        rc = lib.tl_pupil_position(0, 1, K, _lib.ptr(a), _lib.ptr(b), _lib.ptr(nn), _lib.ptr(zz_), None, None, None, None, st)
+        rc = lib.tl_pupil_position(0, 1, K, _lib.ptr(a), _lib.ptr(b), _lib.ptr(nn), _lib.ptr(zz_), None, None, None, None, 0, st)
         assert rc != 0 and lib.tl_last_error()
     gz = torch.ones(1, device=DEV)
-    assert lib.tl_pupil_position(0, 1, 4, _lib.ptr(c), _lib.ptr(c), _lib.ptr(n), _lib.ptr(z), _lib.ptr(gz), None, None, None, st) != 0
-    assert lib.tl_pupil_position(0, 0, 4, _lib.ptr(c), _lib.ptr(c), _lib.ptr(n), _lib.ptr(z), None, None, None, None, st) != 0      # B < 1
+    assert lib.tl_pupil_position(0, 1, 4, _lib.ptr(c), _lib.ptr(c), _lib.ptr(n), _lib.ptr(z), _lib.ptr(gz), None, None, None, 0, st) != 0
+    assert lib.tl_pupil_position(0, 0, 4, _lib.ptr(c), _lib.ptr(c), _lib.ptr(n), _lib.ptr(z), None, None, None, None, 0, st) != 0      # B < 1
 
 
 def test_pupil_position_of_a_padded_lens_batch():

@@ -23,6 +23,11 @@ from conftest import load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
 
+
+def _used_walk_back(t):
+    from torchoptics_amd import ops
+    return ops.used_walk_back(t)
+
 RAY_CASES = ["G1_singlet_cfg1", "G2_cooke_16x16", "G4_doublet_32x32", "G4_tessar_32x32",
              "G5_cooke_failures", "G6_cooke_aim1", "G10_cooke_noback", "G10_tessar_noback"]
 IN_NAMES = ("in_x", "in_y", "in_z", "in_cx", "in_cy", "in_c", "in_t", "in_mu")
@@ -188,7 +193,7 @@ def test_multi_round_launch_with_ragged_tail(ta):
             try:
                 lv = [dev[i].clone().requires_grad_(True) for i in (5, 6, 7)]
                 x, y, cx, cy, ok, back = ta.trace_skew(*dev[:5], *lv, mask.to(DEV), mode=mode)
-                assert x.grad_fn.use_inv is (algo == "inverse")
+                assert _used_walk_back(x) is (algo == "inverse")
                 ta.compute_rms2d(x, y, ok).backward()
                 grads[algo] = [q.grad.cpu().numpy() for q in lv]
             finally:
@@ -347,7 +352,7 @@ def test_checkpoint_free_backward_vs_reference_autograd(ta, case, mode):
             lv = [ins[i].clone().requires_grad_(True) for i in (2, 4, 5, 6, 7)]
             x, y, cx, cy, ok, back = ta.trace_skew(ins[0], ins[1], lv[0], ins[3], lv[1], lv[2], lv[3], lv[4], mask,
                                                    False, allow, mode=mode)
-            ctx_inv = x.grad_fn.use_inv if hasattr(x.grad_fn, "use_inv") else None
+            ctx_inv = _used_walk_back(x)
             ta.compute_rms2d(x, y, ok).backward()
             res[algo] = ([q.grad.cpu().numpy() for q in lv], ctx_inv)
         finally:
@@ -379,7 +384,7 @@ def test_checkpoint_free_backward_with_dense_upstream_gradients(ta):
     gen = torch.Generator().manual_seed(3)
     wts = [torch.randn(g["x"].shape, generator=gen) for _ in range(4)]
     outs = ta.trace_skew(*ins[:5], *lv, mask, False, allow)
-    assert outs[0].grad_fn.use_inv is True
+    assert _used_walk_back(outs[0]) is True
     loss = sum((o * w.to(DEV)).sum() for o, w in zip(outs[:4], wts))
     got = torch.autograd.grad(loss, lv)
     cpu = [torch.from_numpy(g[n]).double() for n in IN_NAMES]
@@ -434,7 +439,7 @@ def test_walk_back_non_finite_adjoint_falls_back_to_checkpoint_kernel(ta):
             ins, mask, allow = dev_inputs(g)
             lv = [ins[i].clone().requires_grad_(True) for i in (5, 6, 7)]
             x, y, cx, cy, ok, back = ta.trace_skew(*ins[:5], *lv, mask, False, allow)
-            assert x.grad_fn.use_inv is (algo == "inverse")
+            assert _used_walk_back(x) is (algo == "inverse")
             loss = ta.compute_rms2d(x, y, ok)                  # from the fused moments: untouched by the corruption
             if algo == "inverse":
                 buf = x.data.permute(0, 1, 3, 2)               # x is a permuted view of the [1,F,W,P] buffer
@@ -570,7 +575,7 @@ def test_backward_under_saved_tensor_hooks(ta, aggregate):
         ctxm = torch.autograd.graph.save_on_cpu() if hooks else torch.enable_grad()
         with ctxm:
             out = ta.trace_skew(*ins, mask, aggregate, allow)
-            assert out[0].grad_fn.use_inv
+            assert _used_walk_back(out[0])
             loss = ta.compute_rms2d(out[0], out[1], out[4])
             if aggregate:
                 loss = loss + 0.2 * rt.penalty_sum(out[6], 8)

@@ -19,6 +19,11 @@ import torch
 from conftest import load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
+
+
+def _used_walk_back(t):
+    from torchoptics_amd import ops
+    return ops.used_walk_back(t)
 DEV = "cuda:0"
 IN = ("in_x", "in_y", "in_z", "in_cx", "in_cy", "in_c", "in_t", "in_mu")
 
@@ -172,7 +177,7 @@ def test_penalty_walk_back_takes_the_live_rays_and_the_checkpoint_pass_the_dead_
             lv = [ins[i].to(DEV).clone().requires_grad_(True) for i in (2, 4, 5, 6, 7)]
             o = ta.trace_skew(x_in.to(DEV), y_in.to(DEV), lv[0], ins[3].to(DEV), lv[1], lv[2], lv[3], lv[4], mask.to(DEV),
                               "sum", True, mode=mode)
-            assert o[0].grad_fn.use_inv is (algo == "inverse")
+            assert _used_walk_back(o[0]) is (algo == "inverse")
             assert o[1]._tl_spot[0][:, 9].sum().item() == 0      # ... and no ill-conditioned live ray: the walk-back runs
             (ta.compute_rms2d(o[0], o[1], o[4]) + 0.2 * rt.penalty_sum(o[6], S)).backward()
             got[algo] = [q.grad.cpu() for q in lv]

@@ -107,6 +107,40 @@ def _build(OBJ, LIB, extra_flags, force, verbose):
     return LIB
 
 
+EXT = os.path.join(HERE, "_tlx.so")
+
+
+def build_host_extension(force=False, verbose=True):
+    """torchoptics_amd/_tlx.so: the eager host chain (argument normalisation, allocation, the calls into libtltrace.so's
+    C ABI and the autograd nodes around them) as C++ torch::autograd::Functions (csrc/tl_torch.cpp).  Plain host C++ --
+    no device code: compiled with g++ against PyTorch's headers, linked to libtltrace.so next to it (rpath $ORIGIN)."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "tl_torch.cpp")
+    stamp = os.path.join(OBJ, "tl_torch.sha")
+    os.makedirs(OBJ, exist_ok=True)
+    flags = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+             f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-DTORCH_EXTENSION_NAME=_tlx",
+             "-DTORCH_API_INCLUDE_EXTENSION_H"]
+    dig = _digest([src, os.path.join(ROOT, "include", "tl_trace.h")], flags + [torch.__version__])
+    if not force and os.path.exists(EXT) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return EXT
+    cxx = shutil.which("g++") or "g++"
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ([cxx] + flags + [src] + [f"-I{p}" for p in ce.include_paths()] +
+           [f"-I{sysconfig.get_paths()['include']}", f"-I{rocm}/include"] +
+           [f"-L{p}" for p in ce.library_paths()] + [f"-L{rocm}/lib", f"-L{HERE}"] +
+           ["-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-ltorch_python", "-lamdhip64", "-ltltrace",
+            "-Wl,-rpath,$ORIGIN"] + [f"-Wl,-rpath,{p}" for p in ce.library_paths()] + ["-o", EXT])
+    if verbose:
+        print("[tltrace]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return EXT
+
+
 def build_cabi_demo(verbose=True):
     """examples/cabi_demo.bin: a plain C++ host program on the C ABI (no Python, no torch)."""
     src = os.path.join(ROOT, "examples", "cabi_demo.cpp")
@@ -124,4 +158,5 @@ def build_cabi_demo(verbose=True):
 
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv))
+    print(build_host_extension(force="--force" in sys.argv))
     print(build_cabi_demo())

@@ -305,11 +305,15 @@ __global__ __launch_bounds__(kBlock) void spot_seed_kernel(int P, int W, const f
 __device__ float pupil_position_fp32_tree(int K, const float *__restrict__ c, const float *__restrict__ t,
                                           const float *__restrict__ n)
 {
+    // Plain operators under contract(off): every product and sum is rounded on its own.  (HIP's __fmul_rn / __fadd_rn are
+    // inline functions compiled under the translation unit's default, contract(fast): inlined here they would still fuse.)
+#pragma clang fp contract(off)
     float M[TL_MAX_SURFACES][4];
     for (int k = 0; k < K; ++k) {
-        const float r = __fdiv_rn(n[k], n[k + 1]);
-        const float P = __fmul_rn(c[k], __fsub_rn(r, 1.0f));
-        M[k][0] = __fadd_rn(1.0f, __fmul_rn(P, t[k])); M[k][1] = __fmul_rn(r, t[k]); M[k][2] = P; M[k][3] = r;
+        const float r = n[k] / n[k + 1];
+        const float P = c[k] * (r - 1.0f);
+        const float Pt = P * t[k];
+        M[k][0] = 1.0f + Pt; M[k][1] = r * t[k]; M[k][2] = P; M[k][3] = r;
     }
     int cnt = K;
     while (cnt > 1) {
@@ -318,15 +322,14 @@ __device__ float pupil_position_fp32_tree(int K, const float *__restrict__ c, co
             const float a0 = M[i + 1][0], a1 = M[i + 1][1], a2 = M[i + 1][2], a3 = M[i + 1][3];
             const float b0 = M[i][0], b1 = M[i][1], b2 = M[i][2], b3 = M[i][3];
             float *o = M[i >> 1];
-            o[0] = __fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b2));
-            o[1] = __fadd_rn(__fmul_rn(a0, b1), __fmul_rn(a1, b3));
-            o[2] = __fadd_rn(__fmul_rn(a2, b0), __fmul_rn(a3, b2));
-            o[3] = __fadd_rn(__fmul_rn(a2, b1), __fmul_rn(a3, b3));
+            const float p00 = a0 * b0, q00 = a1 * b2, p01 = a0 * b1, q01 = a1 * b3;
+            const float p10 = a2 * b0, q10 = a3 * b2, p11 = a2 * b1, q11 = a3 * b3;
+            o[0] = p00 + q00; o[1] = p01 + q01; o[2] = p10 + q10; o[3] = p11 + q11;
         }
         if (cnt & 1) { for (int j = 0; j < 4; ++j) M[even >> 1][j] = M[cnt - 1][j]; }
         cnt = (even >> 1) + (cnt & 1);
     }
-    return __fdiv_rn(M[0][1], M[0][0]);
+    return M[0][1] / M[0][0];
 }
 
 __global__ __launch_bounds__(64) void pupil_position_kernel(int B, int K, const float *__restrict__ c,

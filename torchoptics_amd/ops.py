@@ -26,6 +26,49 @@ _default_mode = os.environ.get("TORCHOPTICS_AMD_MODE", "strict")
 _bwd_algo = os.environ.get("TORCHOPTICS_AMD_BWD", "inverse")
 
 
+# host chain: "cpp" = the C++ autograd functions of _tlx.so (csrc/tl_torch.cpp: argument normalisation, allocation,
+# the C-ABI calls and the autograd nodes in C++; the default when the extension is built), "python" = the ctypes
+# wrappers below (same kernels, same numbers; ~2x the host time per step)
+_host = os.environ.get("TORCHOPTICS_AMD_HOST", "cpp")
+_ext_mod = None
+
+
+def set_host_chain(name: str) -> None:
+    global _host
+    if name not in ("cpp", "python"):
+        raise ValueError("host chain must be 'cpp' or 'python'")
+    _host = name
+
+
+def _ext():
+    """The C++ host extension, or None (not built / another ABI / host chain 'python')."""
+    global _ext_mod
+    if _host != "cpp":
+        return None
+    if _ext_mod is None:
+        try:
+            _lib.lib()                                  # libtltrace.so first: clear error when THAT is missing
+            from . import _tlx
+            _ext_mod = _tlx if _tlx.abi_version() == _lib.TL_ABI_VERSION else False
+        except ImportError:
+            _ext_mod = False
+    return _ext_mod or None
+
+
+def host_chain() -> str:
+    """Which host chain trace_skew / compute_rms2d use right now: 'cpp' or 'python'."""
+    return "cpp" if _ext() is not None else "python"
+
+
+def used_walk_back(t: torch.Tensor) -> bool:
+    """Whether the backward of the trace that produced `t` (the x returned by trace_skew) is the walk-back from the
+    forward's outputs (tl_trace_bwd_from_outputs) rather than the checkpoint algorithm."""
+    return bool(getattr(t, "_tl_use_inv"))
+
+
+_last_use_inv = False
+
+
 def set_backward_algorithm(name: str) -> None:
     global _bwd_algo
     if name not in ("checkpoint", "inverse"):
@@ -70,12 +113,27 @@ def enable_timing(on: bool = True) -> None:
     """Record a (start, stop) event pair around every tl_trace_fwd / tl_trace_bwd call."""
     global _timing
     _timing = {"fwd": [], "bwd": []} if on else None
+    if _ext() is not None:
+        _ext().enable_timing(bool(on))
+
+
+def timing_counts() -> dict:
+    """C-ABI trace calls recorded since enable_timing(True): {'fwd': n, 'bwd': n} (either host chain)."""
+    out = {k: len(v) for k, v in (_timing or {}).items()}
+    if _ext() is not None and _timing is not None:
+        f, b = _ext().timing_counts()
+        out = {"fwd": out.get("fwd", 0) + f, "bwd": out.get("bwd", 0) + b}
+    return out
 
 
 def timing_ms() -> dict:
     """Mean GPU milliseconds per call since enable_timing(); synchronises the device."""
     torch.cuda.synchronize()
-    return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None) for k, v in (_timing or {}).items()}
+    out = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None) for k, v in (_timing or {}).items()}
+    if _ext() is not None and _timing is not None:
+        f, b = _ext().timing_ms()
+        out = {"fwd": f if f >= 0 else out.get("fwd"), "bwd": b if b >= 0 else out.get("bwd")}
+    return out
 
 
 class _Timed:
@@ -215,6 +273,8 @@ class TraceFunction(torch.autograd.Function):
                                   _lib.ptr(opd), _lib.ptr(stacks), _lib.ptr(moments), _lib.ptr(ws), ws.numel(),
                                   _stream_ptr(dev))
         _lib.check(rc, "tl_trace_fwd")
+        global _last_use_inv
+        _last_use_inv = use_inv
         fwd_out = (fp[0], fp[1], fp[2], fp[3], bp[0], moments) if use_inv else (None,) * 6
         ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, *fwd_out,
                               n_index if want_opd else None, hits)
@@ -415,3 +475,23 @@ class PupilPositionFunction(torch.autograd.Function):
                                               _stream_ptr(c.device))
         _lib.check(rc, "tl_pupil_position (backward)")
         return g_c, g_t, g_n, None
+
+
+# ------------------------------------------------------------------------------------------ entry points of the host chain
+def trace_cpp(ext, x, y, z, cx, cy, c, t, mu, mask, kappa, poly, kind, n_index, allow_back, mode, want_rays, want_opd,
+              aggregate, want_stacks, moments_x):
+    """The trace through the C++ host extension: the arguments exactly as trace_skew received them (their broadcast
+    shapes are normalised in C++).  Returns (the nine outputs of TraceFunction, use_inv)."""
+    flags = ((ext.ALLOW_BACK if allow_back else 0) | (ext.WANT_RAYS if want_rays else 0) | (ext.WANT_OPD if want_opd else 0)
+             | (ext.AGGREGATE if aggregate else 0) | (ext.WANT_STACKS if want_stacks else 0)
+             | (ext.MOMENTS_X if moments_x else 0) | (ext.INVERSE if _bwd_algo == "inverse" else 0))
+    out = ext.trace(x, y, z, cx, cy, c, t, mu, mask, kappa, poly, kind, n_index, flags, _MODES[mode], ASPH_HIT_SLOTS)
+    return out, ext.last_use_inv()
+
+
+def spot_rms(moments, n_per_field, n_lens=1):
+    """compute_rms2d on the moments (SpotRmsFunction), through the C++ host extension when it is there."""
+    ext = _ext()
+    if ext is not None and moments.is_cuda:
+        return ext.spot_rms(moments, float(n_per_field), int(n_lens))
+    return SpotRmsFunction.apply(moments, n_per_field, n_lens)

@@ -235,6 +235,23 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
             return _trace_skew_in_lens_chunks(max(1, _MAX_GRID_ROWS // rows_per_lens), B, x, y, z, cx, cy, c, t, mu, mask,
                                               aggregate, allow_backward_rays, mode, want_rays, kappa, poly, surf_kind,
                                               n_index, want_opd, x_moments)
+    ext = ops._ext()
+    if ext is not None:
+        # the C++ host chain: shapes are normalised, outputs allocated and the autograd node built in csrc/tl_torch.cpp
+        S = c.shape[-1]
+        kap = pol = kind = None
+        if kappa is not None or poly is not None:
+            kap = kappa if kappa is not None else torch.zeros(1, S, device=c.device)
+            pol = poly if poly is not None else torch.zeros(1, S, 4, device=c.device)
+            kind = surf_kind
+            if kind is None:
+                kind = (kap.detach().reshape(-1, S) != 0) | (pol.detach().reshape(-1, S, 4) != 0).any(dim=-1)
+            kind = torch.as_tensor(kind, device=c.device)
+        out, use_inv = ops.trace_cpp(ext, x, y, z, cx, cy, c, t, mu, mask, kap, pol, kind, n_index if want_opd else None,
+                                     bool(allow_backward_rays), mode or ops.get_default_mode(), want_rays, bool(want_opd),
+                                     bool(aggregate), bool(aggregate is True and want_rays), bool(x_moments))
+        n_pw = max(x.shape[2], y.shape[2]) * max(x.shape[3], y.shape[3], mu.shape[3])
+        return _trace_result(out, use_inv, want_rays, want_opd, aggregate, x_moments, n_pw, B)
     x, y, z, cx, cy = (_as_f32(a, n) for a, n in ((x, 'x'), (y, 'y'), (z, 'z'), (cx, 'cx'), (cy, 'cy')))
     c, t, mu = _as_f32(c, 'c'), _as_f32(t, 't'), _as_f32(mu, 'mu')
     for a, n in ((x, 'x'), (y, 'y'), (cx, 'cx'), (cy, 'cy'), (z, 'z')):
@@ -278,11 +295,17 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
     out = ops.TraceFunction.apply(x_e, y_e, zv, cx2, cy2, c2, t2, mu3, kap, pol, mask_u8, kind_u8, nidx,
                                   bool(allow_backward_rays), mode or ops.get_default_mode(), want_rays, bool(want_opd),
                                   bool(aggregate), bool(aggregate is True and want_rays), bool(x_moments))
+    return _trace_result(out, ops._last_use_inv, want_rays, want_opd, aggregate, x_moments, P * W, B)
+
+
+def _trace_result(out, use_inv, want_rays, want_opd, aggregate, x_moments, n_pw, B):
+    """The tuple trace_skew returns, from the nine outputs of the trace function."""
     xo, yo, cxo, cyo, ok, back, moments, opd, stk = out
     if want_rays:
         # remember which moments belong to these rays (checked by identity + version in compute_rms2d):
         # [B*F, TL_NMOM], lens-major
-        yo._tl_spot = (moments, ok, yo._version, P * W, bool(x_moments))
+        yo._tl_spot = (moments, ok, yo._version, n_pw, bool(x_moments))
+        xo._tl_use_inv = bool(use_inv)                 # which backward algorithm this trace will take (ops.used_walk_back)
         res = (xo, yo, cxo, cyo, ok, back)
         if want_opd:
             res += (opd,)
@@ -415,7 +438,7 @@ def compute_rms2d(x, y, ray_ok, group=None, n_per_field: Optional[int] = None):
         if n_per_field is None:
             n_per_field = n_local * torch.distributed.get_world_size(group)
     if moments.is_cuda:
-        return ops.SpotRmsFunction.apply(moments, n_per_field or n_local).to(y.dtype)
+        return ops.spot_rms(moments, n_per_field or n_local).to(y.dtype)
     return rms_from_moments(moments, n_per_field or n_local).to(y.dtype)
 
 
@@ -432,7 +455,7 @@ def compute_rms2d_batch(x, y, ray_ok):
         moments = ops.SpotMomentsFunction.apply(fold(x), fold(y), fold(ray_ok))
         n_local = y.shape[2] * y.shape[3]
     if moments.is_cuda:
-        return ops.SpotRmsFunction.apply(moments, n_local, B).reshape(B).to(y.dtype)
+        return ops.spot_rms(moments, n_local, B).reshape(B).to(y.dtype)
     m = moments.view(B, F, -1)
     mean = m[..., 0] / n_local
     var = (m[..., 2] - 2 * mean * m[..., 1] + mean * mean * m[..., 3]) / n_local
