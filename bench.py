@@ -122,9 +122,10 @@ def workload(name, device, world, rank, log2_pupil, fields=None, wl=None):
 class Job:
     """One workload resident on this rank's GPU and the step that is timed."""
 
-    def __init__(self, name, device, world, rank, group, log2_pupil=None, fields=None, wl=None):
+    def __init__(self, name, device, world, rank, group, log2_pupil=None, fields=None, wl=None, penalty_rate=None):
         self.args, self.meta, self.extra = workload(name, device, world, rank, log2_pupil, fields, wl)
         self.name, self.group, self.world = name, group, world
+        self.penalty_rate = penalty_rate        # not None: the real caller's loss rms + penalty_rate * sumQ (aggregate='sum')
         self.leaves = [self.args[k] for k in LEAF_NAMES if k in self.args]
         self.asph = {k: self.args[k] for k in ("kappa", "poly") if k in self.args}
         self.n_per_field_total = self.meta["P_total"] * self.meta["W"]
@@ -137,6 +138,12 @@ class Job:
         a = self.args
         for p in self.leaves:
             p.grad = None
+        if self.penalty_rate is not None:
+            # optics_simulator_lite.py:430-450: loss_unsup = rms + penalty_rate * sumQ, sumQ from the fused penalty sums
+            out = ta.trace_skew(a["x"], a["y"], a["z"], a["cx"], a["cy"], a["c"], a["t"], a["mu"], a["mask"], "sum", **self.asph)
+            rms = ta.compute_rms2d(out[0], out[1], out[4], group=self.group, n_per_field=self.n_per_field_total)
+            (rms + self.penalty_rate * ta.ray_tracing.penalty_sum(out[6], self.meta["S"])).backward()
+            return rms.detach()
         x, y, cx, cy, ok, back = ta.trace_skew(a["x"], a["y"], a["z"], a["cx"], a["cy"], a["c"], a["t"], a["mu"],
                                                a["mask"], **self.asph)
         rms = ta.compute_rms2d(x, y, ok, group=self.group, n_per_field=self.n_per_field_total)
@@ -393,6 +400,21 @@ def main():
                     _, e["grad_rel_err_vs_pytorch_autograd"] = cpu_leg(j2.args, j2.meta, min(a.cpu_log2_rays, 18), a.mode,
                                                                        time_it=False)
             also[wname] = e
+            del j2
+            torch.cuda.empty_cache()
+
+    # the real caller's loss (rms + 0.2 sumQ, aggregate='sum') on the headline lens and on its all-spherical variant
+    if solo and not a.no_also and a.workload == "cfg3a" and a.log2_pupil is None:
+        for wname in ("cfg3a", "cfg3"):
+            log(f"also: {wname} with the penalty term")
+            j2 = Job(wname, device, world, rank, group, penalty_rate=0.2)
+            t2, km2, r2 = timed(j2, a.mode, a.steps, a.warmup, a.repeats, a.graph, a.backend, device)
+            also[wname + "_full_loss"] = dict(**summarize(j2, t2, a.steps), fwd_kernel_ms=km2.get("fwd"), bwd_kernel_ms=km2.get("bwd"),
+                                              rays=j2.rays_total, rows=j2.meta["S"], rms=float(r2.item()), arith_mode=a.mode,
+                                              hip_graph=bool(a.graph),
+                                              workload=f"{wname}: loss_unsup = rms + 0.2 sumQ (optics_simulator_lite.py:430-450), "
+                                                       "aggregate='sum', fwd+bwd; backward = walk-back of the live rays + checkpoint "
+                                                       "pass over the rays that died on the way")
             del j2
             torch.cuda.empty_cache()
 

@@ -250,12 +250,32 @@ def _sag_terms(c, kappa, a, rho):
     return sag, dsag, bad
 
 
+def conic_hit(c, kappa, r: RayBundle):
+    """Closed-form intersection of the ray with the CONIC part of the surface: the quadric
+    c (x^2 + y^2 + K z^2) - 2 z = 0, K = 1 + kappa (the sag formula solved for the surface), along the ray
+    A s^2 + 2 B s + C = 0 with A = c (d.d)_K, B = c (r.d)_K - cz, C = c (r.r)_K - 2 z; the root nearer the vertex plane in
+    its cancellation-free form s = C / (-B + sqrt(B^2 - A C)).  For kappa = 0 this is sphere_hit's distance (the same
+    quadratic written differently).  Returns (miss, s): miss = the ray does not meet the quadric."""
+    K = 1 + kappa
+    e = -((r.x * r.cx + r.y * r.cy) + K * (r.z * r.cz))
+    dd = (r.cx * r.cx + r.cy * r.cy) + K * (r.cz * r.cz)
+    rr = (r.x * r.x + r.y * r.y) + K * (r.z * r.z)
+    bq = c * e + r.cz
+    cq = c * rr - 2 * r.z
+    disc = bq * bq - (c * dd) * cq
+    miss = disc - EPS < 0
+    s = cq / (bq + _sqrt(torch.where(miss, torch.ones_like(disc), disc)))
+    return miss, s
+
+
 def asphere_hit(c, kappa, a, r: RayBundle):
-    """Newton iteration on the ray parameter s from the closed-form sphere hit.
+    """Newton iteration on the ray parameter s from the closed-form hit on the conic part of the surface (round 3; the
+    first definition started from the base SPHERE and called a ray that misses that sphere a miss even where it meets
+    the conic -- a paraboloid or hyperboloid reaches further out than its vertex sphere).
 
     Returns (miss, s, X, Y, dsag, rho): hit point (X, Y), d sag / d rho there.
     """
-    miss0, d0, _, _ = sphere_hit(c, r)
+    miss0, d0 = conic_hit(c, kappa, r)
     s = torch.where(miss0, torch.zeros_like(d0), d0)
     tol = NEWTON_TOL if s.dtype == torch.float32 else 1e-13
     for _ in range(NEWTON_ITERS):

@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--aggregate", action="store_true", help="penalty term (aggregate='sum')")
     ap.add_argument("--hit-slots", type=int, default=4, help="aspheric hit slots handed to the walk-back (0 = Newton)")
     ap.add_argument("--skip", default="", help="comma list of fwd,bwd,bwd_inv not to time")
+    ap.add_argument("--asph-zero", action="store_true",
+                    help="all-spherical workload through the ASPHERIC kernel variants: kappa = poly = 0 and no row marked "
+                         "aspheric (what the variants cost on spherical rows)")
     a = ap.parse_args()
     import bench
     from torchoptics_amd import _lib, ops
@@ -46,11 +49,11 @@ def main():
     cxv, cyv = args["cx"].reshape(1, -1).contiguous(), args["cy"].detach().reshape(1, -1).contiguous()
     mu2 = args["mu"].detach().reshape(-1, S).expand(W, S).contiguous()
     mask = args["mask"].reshape(-1).to(torch.uint8).contiguous()
-    asph = "kappa" in args
+    asph = "kappa" in args or a.asph_zero
     kap = pol = kind = hits = None
     if asph:
-        kap = args["kappa"].detach().reshape(S).contiguous()
-        pol = args["poly"].detach().reshape(S, 4).contiguous()
+        kap = args["kappa"].detach().reshape(S).contiguous() if "kappa" in args else torch.zeros(S, device=dev)
+        pol = args["poly"].detach().reshape(S, 4).contiguous() if "poly" in args else torch.zeros(S, 4, device=dev)
         kind = ((kap != 0) | (pol != 0).any(dim=1)).to(torch.uint8).contiguous()
         if a.hit_slots:
             hits = torch.empty((a.hit_slots, 2, 1, F, W, P), dtype=torch.float32, device=dev)
