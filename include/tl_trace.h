@@ -232,6 +232,25 @@ int tl_spot_seed(int32_t device, int32_t F, int32_t P, int32_t W,
 int tl_pupil_position(int32_t device, int32_t B, int32_t K, const float *c, const float *t, const float *n, float *z,
                       const float *g_z, float *g_c, float *g_t, float *g_n, int32_t mode, void *stream);
 
+/*
+ * Ray aiming, one iteration (RayTracer.ray_aiming, ray_tracing_lite.py:129-208, with compute_pupil_radius :834-844,
+ * ray_aiming_mode 'real'): per (lens, field, wavelength) the three 'tee' rays -- bottom and top meridional, +x sagittal --
+ * are traced to the stop through the K rows in front of it, one Newton step each brings them to where an ideal pupil
+ * would put them (stop radius = height of the on-axis d-line marginal ray), and the affine pupil map through the
+ * corrected rays is returned:   x_pupil' = x_pupil * x_scale,   y_pupil' = y_pupil * y_scale + y_offset.
+ * One thread per (lens, field, wavelength), fp64 in registers, Jacobian by central differences (the reference:
+ * two eager traces + an autograd pass, ~60 tensor ops per call).  No gradient: the reference aims a detached lens (:108).
+ *   c, t [B,K]; n [B,K,W] refractive index behind each row at the tracer's wavelengths, n_d [B,K] at the d line (rows
+ *   behind a lens' own stop padded: c = 0, t = 0, n = 1); mask [B,K] (backward-ray test, :626-632); kappa [B,K],
+ *   poly [B,K,TL_MAX_POLY], surf_kind [B,K] nullable (aspheric rows); z [B] pupil position; hfov [B] half field of view
+ *   (rad), fields [F] relative field heights (cy = sin(hfov * field), :116-118); epd [B];
+ *   x_scale, y_scale, y_offset [B,F,W] float outputs.
+ */
+int tl_ray_aim(int32_t device, int32_t B, int32_t F, int32_t W, int32_t K, const float *c, const float *t, const float *n,
+               const float *n_d, const uint8_t *mask, const float *kappa, const float *poly, const uint8_t *surf_kind,
+               const float *z, const float *hfov, const float *fields, const float *epd, int32_t allow_backward,
+               float *x_scale, float *y_scale, float *y_offset, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

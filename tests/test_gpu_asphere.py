@@ -441,3 +441,45 @@ def test_sag_and_normal_of_conics_against_their_closed_forms(ta, kappa):
     # the first height of this fan, 2e-7 at its edge
     tol = 2e-6 + 1.5e-7 / np.maximum(want_th * (np.pi / 2), 1e-6) / (np.pi / 2)
     assert (np.abs(got_th - want_th)[1:] <= tol[1:]).all()
+
+
+@pytest.mark.parametrize("variant", [True, "strong"])
+@pytest.mark.parametrize("algo", ["inverse", "checkpoint"])
+def test_launch_condition_gradients_on_the_two_asphere_double_gauss(ta, variant, algo):
+    """d rms / dz and d rms / dcy of BASELINE configs[2]'s own prescription (cfg3a, and its
+    strong-asphere variant) chain into d/dc, d/dt of every row before the stop, and nothing gated them on this lens.
+    Both are residuals ~1e-3 of their per-ray terms: gate = max(3 x the oracle's own fp32-vs-fp64 distance, 3e-5)
+    against the oracle's fp64 autograd; the lens parameters (c, t, mu, kappa, poly) at 2e-5."""
+    from oracle import trace_oracle as orc
+    from torchoptics_amd import ops, prescriptions as P
+    lens, specs, _ = P.double_gauss(DEV, requires_grad=False, aspheres=variant)
+    tr = ta.RayTracer(mode="circular", n_rays=(64, 64), rel_fields=(0.707,), wavelengths=("d",), default_device=DEV)
+    with torch.no_grad():
+        a = tr.assemble(specs, lens)
+    names = ("z", "cy", "c", "t", "mu", "kappa", "poly")
+    kap, pol = a["kappa"].reshape(-1), a["poly"].reshape(-1, 4)
+    kind = ((kap != 0) | (pol != 0).any(dim=1)).int().tolist()
+    res = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        lv = [a[k].detach().cpu().to(dt).clone().requires_grad_(True) for k in ("z", "cy", "c", "t", "mu")]
+        lv += [kap.cpu().to(dt).clone().requires_grad_(True), pol.cpu().to(dt).clone().requires_grad_(True)]
+        o = orc.trace_skew_general(a["x"].cpu().to(dt), a["y"].cpu().to(dt), lv[0], a["cx"].cpu().to(dt), lv[1], lv[2], lv[3], lv[4],
+                                   a["mask"].cpu(), lv[5], lv[6], kind, ieee_sqrt=(dt == torch.float32))
+        assert o[4].all()
+        orc.compute_rms2d(o[0], o[1], o[4]).backward()
+        res[tag] = [q.grad for q in lv]
+    _algo(ops, algo)
+    try:
+        lv = [a[k].detach().clone().requires_grad_(True) for k in ("z", "cy", "c", "t", "mu")]
+        lv += [kap.clone().requires_grad_(True), pol.clone().requires_grad_(True)]
+        x, y, cx, cy, ok, back = ta.trace_skew(a["x"], a["y"], lv[0], a["cx"], lv[1], lv[2], lv[3], lv[4], a["mask"],
+                                               kappa=lv[5], poly=lv[6])
+        assert ops.used_walk_back(x) is (algo == "inverse") and ok.all().item()
+        ta.compute_rms2d(x, y, ok).backward()
+    finally:
+        _algo_reset(ops)
+    for n, q, g32, g64 in zip(names, lv, res["f32"], res["f64"]):
+        e64, noise = rel_l2(q.grad.cpu().numpy(), g64.numpy()), rel_l2(g32.numpy(), g64.numpy())
+        print(f"cfg3a[{variant}] {algo} d/d{n}: vs fp64 {e64:.2e} (oracle fp32 itself {noise:.2e})")
+        lim = max(3 * noise, 3e-5) if n in ("z", "cy") else 2e-5 + 2 * noise
+        assert e64 <= lim, f"{algo} d/d{n}: {e64:.2e} vs oracle fp32 noise {noise:.2e}"

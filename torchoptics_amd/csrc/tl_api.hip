@@ -382,6 +382,147 @@ __global__ __launch_bounds__(64) void pupil_position_kernel(int B, int K, const 
     g_n[0] = (float)carry_n;
 }
 
+// ---------------------------------------------------------------- ray aiming (ray_tracing_lite.py:129-208, 834-844)
+// One thread per (lens, field, wavelength): everything the reference's RayTracer.ray_aiming does with ~60 tensor ops, two
+// traces and an autograd pass over 3 rays per thread -- in fp64, in registers:
+//   rs       height of the marginal ray (pupil y = 1, on axis, d line) at the stop                 (compute_pupil_radius :834-844)
+//   tee rays bottom / top meridional and +x sagittal ray (pupil (0,-1), (0,1), (1,0)) traced to the stop through the
+//            rows in front of it, positions over rs                                               (:169-176)
+//   J        d(xs_rel + ys_rel)/d(pupil x) of the sagittal ray, d(.)/d(pupil y) of the two meridional ones -- the
+//            reference backpropagates ones through xs_rel and ys_rel into the same .grad (:177-181); here central
+//            differences in fp64 (h = 1e-4 of the pupil radius: ~1e-9 relative)
+//   remap    one Newton step per ray, non-finite steps dropped, then the affine map of the pupil          (:183-208)
+// A dead ray (miss / total internal reflection on the way) takes no step, as in the reference (its zeroed outputs and
+// zero Jacobian give a non-finite step, which is dropped).
+struct AimLens {
+    int K;
+    const float *c, *t, *n;          // c, t [K]; n [K][W] indices behind each row for the tracer's wavelengths
+    const float *n_d;                // [K] d-line indices (marginal ray)
+    const uint8_t *mask, *kind;      // [K]; kind nullable
+    const float *kappa, *poly;       // [K], [K][4]; nullable with kind
+    int W;
+    bool allow_back;
+};
+
+// fp64 restatement of one ray through the rows (SURVEY Appendix A op for op, aspheric rows by Newton to convergence).
+// w < 0: the d line.  Returns false for a ray the forward would have flagged not ok.
+__device__ bool aim_trace(const AimLens &L, int w, double x, double y, double z, double cx, double cy, double &xo, double &yo)
+{
+    const double eps = 1e-6;
+    double cz = sqrt((1.0 - cx * cx) - cy * cy);
+    double n_prev = 1.0;
+    for (int k = 0; k < L.K; ++k) {
+        const double c = (double)L.c[k], t = (double)L.t[k];
+        const double n_k = (double)(w < 0 ? L.n_d[k] : L.n[(size_t)k * L.W + w]);
+        const double mu = (double)((float)n_prev / (float)n_k);          // the host chain forms mu in fp32 (:123)
+        n_prev = n_k;
+        double X, Y, Z, dz, cos_i, nx, ny, nz;
+        const bool asph = L.kind && L.kind[k];
+        if (!asph) {
+            const double e = -((x * cx + y * cy) + z * cz);
+            const double mz = z + e * cz;
+            const double m2 = ((x * x + y * y) + z * z) - e * e;
+            const double tmp = c * m2 - 2.0 * mz;
+            const double cos2 = cz * cz - c * tmp;
+            if (cos2 - eps < 0.0) return false;
+            cos_i = sqrt(cos2);
+            const double d = e + tmp / (cz + cos_i);
+            dz = d * cz;
+            X = x + d * cx; Y = y + d * cy; Z = z + dz;
+            nx = -c * X; ny = -c * Y; nz = 1.0 - c * Z;                  // unit normal of the sphere at the hit
+        } else {
+            const double kap = (double)L.kappa[k];
+            const double a0 = (double)L.poly[4 * k], a1 = (double)L.poly[4 * k + 1], a2 = (double)L.poly[4 * k + 2], a3 = (double)L.poly[4 * k + 3];
+            const double Kc = 1.0 + kap;
+            const double e = -((x * cx + y * cy) + Kc * (z * cz));
+            const double dd = (cx * cx + cy * cy) + Kc * (cz * cz);
+            const double rr = (x * x + y * y) + Kc * (z * z);
+            const double bq = c * e + cz, cq = c * rr - 2.0 * z;
+            const double disc = bq * bq - (c * dd) * cq;
+            if (disc - eps < 0.0) return false;
+            double s = cq / (bq + sqrt(disc)), dsag = 0.0, rho = 0.0, F = 0.0;
+            bool bad = false;
+            for (int it = 0; it < 12; ++it) {
+                X = x + s * cx; Y = y + s * cy; Z = z + s * cz;
+                rho = X * X + Y * Y;
+                const double q2 = 1.0 - Kc * c * c * rho;
+                bad = q2 - eps < 0.0;
+                const double q = sqrt(bad ? 1.0 : q2);
+                const double sag = c * rho / (1.0 + q) + rho * rho * (a0 + rho * (a1 + rho * (a2 + rho * a3)));
+                dsag = c / (2.0 * q) + rho * (2.0 * a0 + rho * (3.0 * a1 + rho * (4.0 * a2 + rho * (5.0 * a3))));
+                F = Z - sag;
+                if (fabs(F) <= 1e-13 * (1.0 + fabs(Z))) break;
+                s -= F / (cz - dsag * (2.0 * (X * cx + Y * cy)));
+            }
+            if (bad || !(fabs(F) <= 1e-9 * (1.0 + fabs(Z)))) return false;
+            dz = s * cz;
+            const double m = 2.0 * dsag, inv_n = 1.0 / sqrt(1.0 + m * m * rho);
+            nx = -(m * X) * inv_n; ny = -(m * Y) * inv_n; nz = inv_n;
+            cos_i = (cx * nx + cy * ny) + cz * nz;
+        }
+        // refraction (vector form; for a sphere it is apply_snell_spherical :554-568 written with the normal)
+        const double cos2_t = 1.0 - (mu * mu) * (1.0 - cos_i * cos_i);
+        if (cos2_t - eps < 0.0) return false;
+        const double g = sqrt(cos2_t) - mu * cos_i;
+        const double cx3 = mu * cx + g * nx, cy3 = mu * cy + g * ny;
+        const double czsq = 1.0 - (cx3 * cx3 + cy3 * cy3);
+        if (k > 0 && L.mask[k - 1] && dz < 0.0 && !L.allow_back) return false;       // :626-632
+        if (czsq - eps < 0.0) return false;
+        x = X; y = Y; z = Z - t;
+        cx = cx3; cy = cy3; cz = sqrt(czsq);
+    }
+    const double dzi = -z, dist = dzi / cz;                                          // :660-663
+    if (L.mask[L.K - 1] && dzi < 0.0 && !L.allow_back) return false;
+    xo = x + dist * cx; yo = y + dist * cy;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void ray_aim_kernel(int B, int F, int W, int K, const float *__restrict__ c,
+                                                     const float *__restrict__ t, const float *__restrict__ n,
+                                                     const float *__restrict__ n_d, const uint8_t *__restrict__ mask,
+                                                     const float *__restrict__ kappa, const float *__restrict__ poly,
+                                                     const uint8_t *__restrict__ kind, const float *__restrict__ z,
+                                                     const float *__restrict__ hfov, const float *__restrict__ fields,
+                                                     const float *__restrict__ epd, int allow_back,
+                                                     float *__restrict__ x_scale, float *__restrict__ y_scale,
+                                                     float *__restrict__ y_offset)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= B * F * W) return;
+    const int w = i % W, f = (i / W) % F, b = i / (W * F);
+    AimLens L;
+    L.K = K; L.W = W; L.allow_back = allow_back != 0;
+    L.c = c + (size_t)b * K; L.t = t + (size_t)b * K; L.n = n + (size_t)b * K * W; L.n_d = n_d + (size_t)b * K;
+    L.mask = mask + (size_t)b * K;
+    L.kind = kind ? kind + (size_t)b * K : nullptr;
+    L.kappa = kind ? kappa + (size_t)b * K : nullptr;
+    L.poly = kind ? poly + (size_t)b * K * 4 : nullptr;
+    const double z0 = (double)z[b], half = 0.5 * (double)epd[b];
+    const double cy0 = sin((double)(hfov[b] * fields[f]));               // the correctly rounded sine of the fp32 angle (assemble)
+    const double cyf = (double)(float)cy0;
+    double xs, rs = 0.0;
+    const bool ok_m = aim_trace(L, -1, 0.0, half, z0, 0.0, 0.0, xs, rs);  // compute_pupil_radius: marginal ray, on axis, d line
+    const double h = 1e-4;
+    double step[3] = {0.0, 0.0, 0.0};                                     // Newton step of (bottom y, top y, sagittal x)
+    const double px[3] = {0.0, 0.0, 1.0}, py[3] = {-1.0, 1.0, 0.0};
+    for (int r = 0; r < 3 && ok_m; ++r) {
+        double x0, y0, xa, ya, xb, yb;
+        const double ex = (r == 2) ? h : 0.0, ey = (r == 2) ? 0.0 : h;
+        const bool ok = aim_trace(L, w, px[r] * half, py[r] * half, z0, 0.0, cyf, x0, y0) &&
+                        aim_trace(L, w, (px[r] + ex) * half, (py[r] + ey) * half, z0, 0.0, cyf, xa, ya) &&
+                        aim_trace(L, w, (px[r] - ex) * half, (py[r] - ey) * half, z0, 0.0, cyf, xb, yb);
+        if (!ok) continue;
+        const double j = ((xa + ya) - (xb + yb)) / (2.0 * h * rs);        // d(xs_rel + ys_rel) / d(pupil coordinate)
+        const double pos = ((r == 2) ? x0 : y0) / rs, want = (r == 2) ? 1.0 : py[r];
+        const double d = -(pos - want) / j;
+        step[r] = (d - d == 0.0) ? d : 0.0;                               // non-finite -> no step (:185-186)
+    }
+    // affine pupil map through the corrected tee rays (:187-208)
+    x_scale[i] = (float)(1.0 + step[2]);
+    y_scale[i] = (float)(((1.0 + step[1]) - (-1.0 + step[0])) / 2.0);
+    y_offset[i] = (float)(((-1.0) * step[1] - (1.0) * step[0]) / (-2.0));
+}
+
 extern "C" {
 
 int tl_version(void) { return TL_ABI_VERSION; }
@@ -618,6 +759,26 @@ int tl_pupil_position(int32_t device, int32_t B, int32_t K, const float *c, cons
                        mode == TL_MODE_STRICT ? 1 : 0);
     const int herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "pupil_position_kernel launch");
+    return TL_OK;
+}
+
+int tl_ray_aim(int32_t device, int32_t B, int32_t F, int32_t W, int32_t K, const float *c, const float *t, const float *n,
+               const float *n_d, const uint8_t *mask, const float *kappa, const float *poly, const uint8_t *surf_kind,
+               const float *z, const float *hfov, const float *fields, const float *epd, int32_t allow_backward,
+               float *x_scale, float *y_scale, float *y_offset, void *stream)
+{
+    if (B < 1 || F < 1 || W < 1 || K < 1 || K > TL_MAX_SURFACES || !c || !t || !n || !n_d || !mask || !z || !hfov || !fields ||
+        !epd || !x_scale || !y_scale || !y_offset)
+        return fail(TL_EINVAL, "tl_ray_aim: bad argument");
+    if ((surf_kind != nullptr) != (kappa != nullptr) || (surf_kind != nullptr) != (poly != nullptr))
+        return fail(TL_EINVAL, "tl_ray_aim: surf_kind, kappa and poly must be given together (or all NULL)");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    const int nthr = B * F * W;
+    hipLaunchKernelGGL(ray_aim_kernel, dim3((nthr + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, F, W, K, c, t, n, n_d, mask,
+                       kappa, poly, surf_kind, z, hfov, fields, epd, allow_backward, x_scale, y_scale, y_offset);
+    const int herr = (int)hipGetLastError();
+    if (herr) return hip_fail(herr, "ray_aim_kernel launch");
     return TL_OK;
 }
 
