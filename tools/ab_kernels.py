@@ -125,7 +125,7 @@ def main():
                 elif key != "fwd":
                     ref.setdefault(name, {})[key] = gpar.clone()
             if rnd == 0:
-                ref[name]["mom"] = mom.clone()
+                ref.setdefault(name, {})["mom"] = mom.clone()
                 for k_ in lib_env.get(name, {}):
                     os.environ.pop(k_, None)
     base = next(iter(libs))
