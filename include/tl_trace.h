@@ -251,6 +251,14 @@ int tl_ray_aim(int32_t device, int32_t B, int32_t F, int32_t W, int32_t K, const
                const float *z, const float *hfov, const float *fields, const float *epd, int32_t allow_backward,
                float *x_scale, float *y_scale, float *y_offset, void *stream);
 
+/*
+ * Diagnostic: quot[i] = a[i] / b[i] and root[i] = sqrt(b[i]) evaluated by the division and square root the trace kernels of
+ * `mode` use.  Strict mode promises the correctly rounded (IEEE) results on the operand ranges of the trace, from shorter
+ * instruction sequences than the compiler's general ones: tests/test_gpu_arith.py holds it to that, bit for bit.
+ */
+int tl_selftest_arith(int32_t device, int32_t mode, const float *a, const float *b, int64_t n, float *quot, float *root,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

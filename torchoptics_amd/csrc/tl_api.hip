@@ -782,4 +782,17 @@ int tl_ray_aim(int32_t device, int32_t B, int32_t F, int32_t W, int32_t K, const
     return TL_OK;
 }
 
+int tl_selftest_arith(int32_t device, int32_t mode, const float *a, const float *b, int64_t n, float *quot, float *root,
+                      void *stream)
+{
+    if (!a || !b || !quot || !root || n < 1) return fail(TL_EINVAL, "tl_selftest_arith: bad argument");
+    if (mode != TL_MODE_STRICT && mode != TL_MODE_FAST) return fail(TL_EINVAL, "unknown mode");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    const int herr = mode == TL_MODE_FAST ? tl_fast::api_selftest_arith(a, b, n, quot, root, (hipStream_t)stream)
+                                          : tl_strict::api_selftest_arith(a, b, n, quot, root, (hipStream_t)stream);
+    if (herr) return hip_fail(herr, "selftest_arith_kernel launch");
+    return TL_OK;
+}
+
 }  // extern "C"

@@ -38,6 +38,7 @@ static inline bool tl_walk_unrolled(int S, int P) { return S >= TL_INVU_MIN && S
                     const float *fcx, const float *fcy, const uint8_t *fok, const double *fmom,       \
                     float *gxin, float *gyin, double *part_inv, double *part_ck, unsigned *poison,    \
                     unsigned token, int nbx, int R, int nbx_ck, int R_ck, hipStream_t st);           \
+    int api_selftest_arith(const float *a, const float *b, int64_t n, float *quot, float *root, hipStream_t st); \
     }
 TL_DECLARE_MODE(tl_strict)
 TL_DECLARE_MODE(tl_fast)

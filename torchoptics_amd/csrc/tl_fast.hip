@@ -17,4 +17,6 @@ int api_bwd_inv(const tl_problem &p, const float *gx, const float *gy, const flo
                 const uint8_t *fok, const double *fmom, float *gxin, float *gyin, double *part_inv, double *part_ck,
                 unsigned *poison, unsigned token, int nbx, int R, int nbx_ck, int R_ck, hipStream_t st)
 { return tl_fast_impl::launch_bwd_inv(p, gx, gy, gcx, gcy, gmom, fx, fy, fcx, fcy, fok, fmom, gxin, gyin, part_inv, part_ck, poison, token, nbx, R, nbx_ck, R_ck, st); }
+int api_selftest_arith(const float *a, const float *b, int64_t n, float *quot, float *root, hipStream_t st)
+{ return tl_fast_impl::launch_selftest_arith(a, b, n, quot, root, st); }
 }
