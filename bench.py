@@ -321,6 +321,34 @@ def grad_report(job, group, backend, device):
                 values={k: job.args[k].grad.detach().reshape(-1).cpu().tolist() for k in names})
 
 
+def full_size_fp64_check(job):
+    """The gradients of the last fp32 step against the SAME fan traced by the double-precision kernels
+    (tl_trace_fwd_f64 / tl_trace_bwd_f64: generic fp64 twins of the trace, checked against the oracle's fp64 autograd in
+    tests/test_gpu_f64.py) at the FULL size of the workload -- the CPU oracle's gradient check stops at 2^20 rays."""
+    import torchoptics_amd as ta
+    names = [k for k in LEAF_NAMES if k in job.args and job.args[k].grad is not None]
+    a64 = {k: (v.detach().double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in job.args.items()}
+    for k in names:
+        a64[k].requires_grad_(True)
+    extra = {k: a64[k] for k in ("kappa", "poly") if k in a64}
+    t0 = time.perf_counter()
+    x, y, cx, cy, ok, back = ta.trace_skew(a64["x"], a64["y"], a64["z"], a64["cx"], a64["cy"], a64["c"], a64["t"], a64["mu"],
+                                           a64["mask"], **extra)
+    rms = ta.compute_rms2d(x, y, ok, group=job.group, n_per_field=job.n_per_field_total)
+    rms.backward()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    def rel(p, q):
+        return float(((p.double() - q).norm() / q.norm().clamp_min(1e-300)).item())
+    per = {k: rel(job.args[k].grad, a64[k].grad) for k in names}
+    lens_groups = [k for k in ("c", "t", "mu", "kappa", "poly") if k in per]
+    return dict(rays=job.rays_local, rms_fp64=float(rms.item()), per_group=per, max_lens_parameters=max(per[k] for k in lens_groups),
+                fp64_step_ms=dt * 1e3,
+                note="norm-relative distance of the fp32 step's gradients from the double-precision kernels' on the whole fan "
+                     "of this rank (before the gradient all-reduce when sharded); z, cy are residual-type gradients")
+
+
 def summarize(job, times, steps):
     med = statistics.median(times)
     return dict(value=job.rays_total * steps / med / 1e6, unit="M rays/s", ms_per_step=med / steps * 1e3,
@@ -363,6 +391,14 @@ def main():
     times, kern_ms, rms = timed(job, a.mode, a.steps, a.warmup, a.repeats, a.graph, a.backend, device)
     head = summarize(job, times, a.steps)
     final_grads = grad_report(job, group, a.backend, device)
+    fp64_full = None
+    if world == 1 and not a.graph:
+        try:
+            job.step()                       # fresh fp32 gradients of one step
+            fp64_full = full_size_fp64_check(job)
+        except Exception as e:               # a checker problem must not cost the measurement
+            fp64_full = dict(error=f"{type(e).__name__}: {e}"[:300])
+        torch.cuda.empty_cache()
     roofline, roofline_valu, kernels, step_bpr = roofline_of(job, kern_ms, a.mode)
     inv = ops.get_backward_algorithm() == "inverse"
     solo = world == 1
@@ -529,6 +565,7 @@ def main():
             "grad_rel_err_vs_pytorch_autograd": grad_check,
             "leaf_grads": leaf_grads,
             "final_grads": final_grads,
+            "grad_vs_fp64_kernels_full_size": fp64_full,
             "other_mode": other,
             "hip_graph_replay": hip_graph,
             "also": also,

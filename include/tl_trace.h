@@ -252,6 +252,23 @@ int tl_ray_aim(int32_t device, int32_t B, int32_t F, int32_t W, int32_t K, const
                float *x_scale, float *y_scale, float *y_offset, void *stream);
 
 /*
+ * Double precision -- RayTracer(double_precision=True) (ray_tracing_lite.py:82-84; the reference crashes there: Specs and
+ * Lens have no .double()).  The same trace, forward and checkpoint backward, entirely in fp64: generic,
+ * untuned kernels (one ray per lane, rolled loops) for reference-quality numbers on the GPU, not for speed.
+ * `p` is a tl_problem whose float-typed pointers (x_in, y_in, z, cx, cy, c, t, mu, kappa, poly) POINT AT DOUBLES, same
+ * shapes and strides (in elements); mask / surf_kind stay uint8; aggregate must be 0, n_index / asph_hits are ignored.
+ * Outputs and gradients as in tl_trace_fwd / tl_trace_bwd with double instead of float (moments [B,F,TL_NMOM] as there,
+ * entry 8 = 0).  Workspace: tl_workspace_bytes_f64(p).
+ */
+size_t tl_workspace_bytes_f64(const tl_problem *p);
+int tl_trace_fwd_f64(const tl_problem *p, double *x, double *y, double *cx, double *cy, uint8_t *ok, uint8_t *back,
+                     double *moments, void *workspace, size_t workspace_bytes, void *stream);
+int tl_trace_bwd_f64(const tl_problem *p, const double *gx, const double *gy, const double *gcx, const double *gcy,
+                     const double *g_moments, double *g_c, double *g_t, double *g_mu, double *g_z, double *g_cx, double *g_cy,
+                     double *g_kappa, double *g_poly, double *g_x_in, double *g_y_in, void *workspace, size_t workspace_bytes,
+                     void *stream);
+
+/*
  * Diagnostic: quot[i] = a[i] / b[i] and root[i] = sqrt(b[i]) evaluated by the division and square root the trace kernels of
  * `mode` use.  Strict mode promises the correctly rounded (IEEE) results on the operand ranges of the trace, from shorter
  * instruction sequences than the compiler's general ones: tests/test_gpu_arith.py holds it to that, bit for bit.

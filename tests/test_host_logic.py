@@ -164,8 +164,7 @@ def test_product_has_no_cpu_path():
 def test_unsupported_options_raise():
     with pytest.raises(ValueError):
         ta.RayTracer(mode="bogus")
-    with pytest.raises(NotImplementedError):
-        ta.RayTracer(mode="circular", double_precision=True)
+    assert ta.RayTracer(mode="circular", double_precision=True).double_precision        # round 3: the fp64 kernels
 
 
 def test_cabi_library_exports_every_declared_symbol():
@@ -173,7 +172,7 @@ def test_cabi_library_exports_every_declared_symbol():
     import ctypes
     from torchoptics_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "tl_trace.h")).read()
-    declared = set(re.findall(r"\b(tl_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(tl_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     dll = _lib.lib()
     for name in declared:

@@ -53,6 +53,9 @@ _SIGNATURES = {
     "tl_spot_rms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, _VP, _VP, _VP, _VP]),
     "tl_spot_seed": (C.c_int, [C.c_int32] * 4 + [_VP] * 3 + [C.c_int64] * 3 + [_VP] * 4),
     "tl_pupil_position": (C.c_int, [C.c_int32] * 3 + [_VP] * 8 + [C.c_int32, _VP]),
+    "tl_workspace_bytes_f64": (C.c_size_t, [C.POINTER(tl_problem)]),
+    "tl_trace_fwd_f64": (C.c_int, [C.POINTER(tl_problem)] + [_VP] * 7 + [_VP, C.c_size_t, _VP]),
+    "tl_trace_bwd_f64": (C.c_int, [C.POINTER(tl_problem)] + [_VP] * 15 + [_VP, C.c_size_t, _VP]),
     "tl_selftest_arith": (C.c_int, [C.c_int32, C.c_int32, _VP, _VP, C.c_int64, _VP, _VP, _VP]),
     "tl_ray_aim": (C.c_int, [C.c_int32] * 5 + [_VP] * 12 + [C.c_int32] + [_VP] * 4),
 }

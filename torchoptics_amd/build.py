@@ -39,6 +39,7 @@ UNITS = {
     "tl_strict.hip": ["-ffp-contract=off"],
     "tl_fast.hip": ["-ffp-contract=fast"],
     "tl_api.hip": [],
+    "tl_f64.hip": [],          # the double-precision twin (generic, untuned)
 }
 DEPS = ["tl_kernels.inc", "tl_common.h", os.path.join("..", "..", "include", "tl_trace.h")]
 
@@ -96,7 +97,7 @@ def _build(OBJ, LIB, extra_flags, force, verbose):
             f.write(dig)
     if jobs:        # the translation units are independent: compile them side by side (each hipcc is one process)
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(len(jobs), 3)) as pool:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 4)) as pool:
             list(pool.map(compile_one, jobs))
     rebuilt = bool(jobs)
     if rebuilt or not os.path.exists(LIB):

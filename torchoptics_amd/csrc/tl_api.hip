@@ -782,6 +782,68 @@ int tl_ray_aim(int32_t device, int32_t B, int32_t F, int32_t W, int32_t K, const
     return TL_OK;
 }
 
+// ---------------------------------------------------------------- double precision (RayTracer(double_precision=True))
+static int check_f64(const tl_problem *p)
+{
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (p->aggregate) return fail(TL_EINVAL, "the double-precision trace has no penalty term (aggregate)");
+    if (p->P < 1) return fail(TL_EINVAL, "the double-precision trace needs P >= 1");
+    return TL_OK;
+}
+
+size_t tl_workspace_bytes_f64(const tl_problem *p)
+{
+    if (!p || p->F < 1 || p->W < 1 || p->S < 1 || p->P < 0) return 0;
+    const Plan pb = plan_bwd(p), pf = plan_fwd(p);
+    const size_t rows = (size_t)rows_bfw(p);
+    const size_t a = rows * pf.nbx * TL_NMOM * sizeof(double), b = rows * pb.nbx * (size_t)(8 * p->S + 3) * sizeof(double);
+    return (a > b ? a : b) + 256;
+}
+
+int tl_trace_fwd_f64(const tl_problem *p, double *x, double *y, double *cx, double *cy, uint8_t *ok, uint8_t *back,
+                     double *moments, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_f64(p);
+    if (rc) return rc;
+    hipError_t e = hipSetDevice(p->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    const Plan pl = plan_fwd(p);
+    double *part = nullptr;
+    if (moments) {
+        const size_t need = (size_t)rows_bfw(p) * pl.nbx * TL_NMOM * sizeof(double);
+        if (!workspace || workspace_bytes < need) return fail(TL_EWORKSPACE, "workspace too small for tl_trace_fwd_f64");
+        part = (double *)workspace;
+    }
+    int herr = tl_f64::launch_fwd(*p, x, y, cx, cy, ok, back, part, pl.nbx, (hipStream_t)stream);
+    if (herr) return hip_fail(herr, "tl_f64::fwd_kernel launch");
+    if (moments) {
+        herr = tl_f64::launch_reduce_moments(*p, part, moments, pl.nbx, (hipStream_t)stream);
+        if (herr) return hip_fail(herr, "tl_f64::reduce_moments_kernel launch");
+    }
+    return TL_OK;
+}
+
+int tl_trace_bwd_f64(const tl_problem *p, const double *gx, const double *gy, const double *gcx, const double *gcy,
+                     const double *g_moments, double *g_c, double *g_t, double *g_mu, double *g_z, double *g_cx, double *g_cy,
+                     double *g_kappa, double *g_poly, double *g_x_in, double *g_y_in, void *workspace, size_t workspace_bytes,
+                     void *stream)
+{
+    int rc = check_f64(p);
+    if (rc) return rc;
+    if (!g_c || !g_t || !g_mu || !g_z || !g_cx || !g_cy) return fail(TL_EINVAL, "a parameter-gradient output is NULL");
+    if (p->surf_kind && (!g_kappa || !g_poly)) return fail(TL_EINVAL, "aspheric rows need g_kappa and g_poly outputs");
+    hipError_t e = hipSetDevice(p->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    const Plan pl = plan_bwd(p);
+    const size_t need = (size_t)rows_bfw(p) * pl.nbx * (size_t)(8 * p->S + 3) * sizeof(double);
+    if (!workspace || workspace_bytes < need) return fail(TL_EWORKSPACE, "workspace too small for tl_trace_bwd_f64");
+    const int herr = tl_f64::launch_bwd(*p, gx, gy, gcx, gcy, g_moments, g_x_in, g_y_in, (double *)workspace, pl.nbx, g_c, g_t, g_mu,
+                                        g_z, g_cx, g_cy, g_kappa, g_poly, (hipStream_t)stream);
+    if (herr) return hip_fail(herr, "tl_f64::bwd_kernel launch");
+    return TL_OK;
+}
+
 int tl_selftest_arith(int32_t device, int32_t mode, const float *a, const float *b, int64_t n, float *quot, float *root,
                       void *stream)
 {

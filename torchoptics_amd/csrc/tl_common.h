@@ -42,3 +42,13 @@ static inline bool tl_walk_unrolled(int S, int P) { return S >= TL_INVU_MIN && S
     }
 TL_DECLARE_MODE(tl_strict)
 TL_DECLARE_MODE(tl_fast)
+
+// double-precision twin (tl_f64.hip): generic, untuned kernels behind tl_trace_fwd_f64 / tl_trace_bwd_f64
+namespace tl_f64 {
+int launch_fwd(const tl_problem &p, double *x, double *y, double *cx, double *cy, uint8_t *ok, uint8_t *back, double *part, int nbx,
+               hipStream_t st);
+int launch_reduce_moments(const tl_problem &p, const double *part, double *mom, int nbx, hipStream_t st);
+int launch_bwd(const tl_problem &p, const double *gx, const double *gy, const double *gcx, const double *gcy, const double *gmom,
+               double *gxin, double *gyin, double *part, int nbx, double *g_c, double *g_t, double *g_mu, double *g_z, double *g_cx,
+               double *g_cy, double *g_kappa, double *g_poly, hipStream_t st);
+}

@@ -365,6 +365,86 @@ class TraceFunction(torch.autograd.Function):
                 None)
 
 
+class TraceFunctionF64(torch.autograd.Function):
+    """The trace in double precision (RayTracer(double_precision=True); tl_trace_fwd_f64 / tl_trace_bwd_f64: generic,
+    untuned fp64 kernels, checkpoint backward).  Same argument shapes as TraceFunction with float64 tensors; no penalty
+    term, no optical path length.  Returns (x, y, cx, cy, ok, back, moments)."""
+
+    @staticmethod
+    def forward(ctx, x_e, y_e, z, cx, cy, c, t, mu, kappa, poly, mask_u8, kind_u8, allow_back, want_rays):
+        for name, ten in (("x", x_e), ("y", y_e), ("z", z), ("cx", cx), ("cy", cy), ("c", c), ("t", t), ("mu", mu)):
+            _require_device(ten, name)
+            if ten.dtype != torch.float64:
+                raise TypeError(f"double-precision trace: `{name}` is {ten.dtype}")
+        dev = x_e.device
+        B, F, P, W = x_e.shape
+        lib = _lib.lib()
+        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, "strict", kappa, poly, kind_u8)
+        nbytes = lib.tl_workspace_bytes_f64(C.byref(prob))
+        ws = _workspace(nbytes, dev)
+        new = lambda dt: torch.empty((B, F, W, P), dtype=dt, device=dev)      # noqa: E731
+        fp = [new(torch.float64) for _ in range(4)] if want_rays else [None] * 4
+        bp = [new(torch.uint8) for _ in range(2)] if want_rays else [None] * 2
+        moments = torch.empty((B * F, TL_NMOM), dtype=torch.float64, device=dev)
+        with _on_device(dev):
+            rc = lib.tl_trace_fwd_f64(C.byref(prob), *[_lib.ptr(b) for b in fp], *[_lib.ptr(b) for b in bp], _lib.ptr(moments),
+                                      _lib.ptr(ws), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "tl_trace_fwd_f64")
+        ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8)
+        ctx.allow_back = allow_back
+        ctx.set_materialize_grads(False)
+        if want_rays:
+            outs = [b.permute(0, 1, 3, 2) for b in fp]
+            flags = [b.view(torch.bool).permute(0, 1, 3, 2) for b in bp]
+        else:
+            outs = [torch.empty(0, dtype=torch.float64, device=dev) for _ in range(4)]
+            flags = [torch.empty(0, dtype=torch.bool, device=dev) for _ in range(2)]
+        ctx.mark_non_differentiable(*flags)
+        return (*outs, *flags, moments)
+
+    @staticmethod
+    def backward(ctx, gx, gy, gcx, gcy, _gok, _gback, gmom):
+        x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8 = ctx.saved_tensors
+        if gx is None and gy is None and gcx is None and gcy is None and gmom is None:
+            return (None,) * 14
+        dev = x_e.device
+        B, F, P, W = x_e.shape
+        S = c.shape[-1]
+        asph = kind_u8 is not None
+        lib = _lib.lib()
+        prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, ctx.allow_back, "strict", kappa, poly, kind_u8)
+        ws = _workspace(lib.tl_workspace_bytes_f64(C.byref(prob)), dev)
+
+        def dense(g):
+            return None if g is None or g.numel() == 0 else _fwp(g.to(torch.float64))
+        gxd, gyd, gcxd, gcyd = dense(gx), dense(gy), dense(gcx), dense(gcy)
+        gmd = None if gmom is None else gmom.to(torch.float64).contiguous()
+        need = ctx.needs_input_grad
+        new = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)     # noqa: E731
+        gxin = new(B, F, W, P) if need[0] else None
+        gyin = new(B, F, W, P) if need[1] else None
+        g_c, g_t, g_mu, g_z, g_cx, g_cy = new(B, S), new(B, S), new(B, W, S), new(B), new(B, F), new(B, F)
+        g_kappa, g_poly = (new(B, S), new(B, S, 4)) if asph else (None, None)
+        with _on_device(dev):
+            rc = lib.tl_trace_bwd_f64(C.byref(prob), _lib.ptr(gxd), _lib.ptr(gyd), _lib.ptr(gcxd), _lib.ptr(gcyd), _lib.ptr(gmd),
+                                      _lib.ptr(g_c), _lib.ptr(g_t), _lib.ptr(g_mu), _lib.ptr(g_z), _lib.ptr(g_cx), _lib.ptr(g_cy),
+                                      _lib.ptr(g_kappa), _lib.ptr(g_poly), _lib.ptr(gxin), _lib.ptr(gyin), _lib.ptr(ws), ws.numel(),
+                                      _stream_ptr(dev))
+        _lib.check(rc, "tl_trace_bwd_f64")
+
+        def fold(g, like):
+            if like.shape[0] == 1 and B > 1:
+                g = g.sum(dim=0, keepdim=True)
+            if like.shape[1] == 1 and F > 1:
+                g = g.sum(dim=1, keepdim=True)
+            return g.reshape(like.shape)
+        return (gxin.permute(0, 1, 3, 2) if need[0] else None, gyin.permute(0, 1, 3, 2) if need[1] else None,
+                g_z.reshape(z.shape) if need[2] else None, fold(g_cx, cx) if need[3] else None, fold(g_cy, cy) if need[4] else None,
+                g_c.reshape(c.shape), g_t.reshape(t.shape), g_mu.reshape(mu.shape),
+                g_kappa.reshape(kappa.shape) if asph else None, g_poly.reshape(poly.shape) if asph else None,
+                None, None, None, None)
+
+
 class SpotRmsFunction(torch.autograd.Function):
     """rms = compute_rms2d on the [F, TL_NMOM] moments (closed form) with its derivative, one tiny
     kernel each way instead of the ~25 elementwise kernels of the eager formula and its autograd.

@@ -191,6 +191,12 @@ def _as_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t if t.dtype == torch.float32 else t.to(torch.float32)
 
 
+def _as_f64(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name} must be a tensor")
+    return t if t.dtype == torch.float64 else t.to(torch.float64)
+
+
 def _dense(a: torch.Tensor) -> torch.Tensor:
     return a if a.is_contiguous() else a.contiguous()
 
@@ -243,7 +249,11 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
             return _trace_skew_in_lens_chunks(max(1, _MAX_GRID_ROWS // rows_per_lens), B, x, y, z, cx, cy, c, t, mu, mask,
                                               aggregate, allow_backward_rays, mode, want_rays, kappa, poly, surf_kind,
                                               n_index, want_opd, x_moments)
-    ext = ops._ext()
+    # double precision (RayTracer(double_precision=True)): the generic fp64 kernels, through the Python host chain below
+    f64 = any(torch.is_tensor(a) and a.dtype == torch.float64 for a in (x, y, z, cy, c, t, mu))
+    if f64 and (aggregate or want_opd):
+        raise NotImplementedError("the double-precision trace has no penalty term and no optical path length")
+    ext = None if f64 else ops._ext()
     if ext is not None:
         # the C++ host chain: shapes are normalised, outputs allocated and the autograd node built in csrc/tl_torch.cpp
         S = c.shape[-1]
@@ -260,6 +270,7 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
                                      bool(aggregate), bool(aggregate is True and want_rays), bool(x_moments))
         n_pw = max(x.shape[2], y.shape[2]) * max(x.shape[3], y.shape[3], mu.shape[3])
         return _trace_result(out, use_inv, want_rays, want_opd, aggregate, x_moments, n_pw, B)
+    _as_f32 = _as_f64 if f64 else globals()["_as_f32"]          # (the normalisation below is dtype-blind)
     x, y, z, cx, cy = (_as_f32(a, n) for a, n in ((x, 'x'), (y, 'y'), (z, 'z'), (cx, 'cx'), (cy, 'cy')))
     c, t, mu = _as_f32(c, 'c'), _as_f32(t, 't'), _as_f32(mu, 'mu')
     for a, n in ((x, 'x'), (y, 'y'), (cx, 'cx'), (cy, 'cy'), (z, 'z')):
@@ -288,9 +299,10 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
     kap = pol = kind_u8 = None
     if kappa is not None or poly is not None:
         # per lens [B,S] / [B,S,4], or one set [S] / [S,4] shared by every lens of the batch
-        kap = (_as_f32(kappa, 'kappa').reshape(-1, S) if kappa is not None else torch.zeros(1, S, device=c.device)).expand(B, S).contiguous()
+        kap = (_as_f32(kappa, 'kappa').reshape(-1, S) if kappa is not None
+               else torch.zeros(1, S, device=c.device, dtype=c.dtype)).expand(B, S).contiguous()
         pol = (_as_f32(poly, 'poly').reshape(-1, S, 4) if poly is not None
-               else torch.zeros(1, S, 4, device=c.device)).expand(B, S, 4).contiguous()
+               else torch.zeros(1, S, 4, device=c.device, dtype=c.dtype)).expand(B, S, 4).contiguous()
         if surf_kind is None:
             surf_kind = (kap.detach() != 0) | (pol.detach() != 0).any(dim=-1)
         kind_u8 = torch.as_tensor(surf_kind, device=c.device).reshape(-1, S).to(torch.uint8).expand(B, S).contiguous()
@@ -300,6 +312,10 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
             raise ValueError("want_opd=True needs n_index [1|B,1,1,W,S+1]")
         nidx = _as_f32(n_index, 'n_index')
         nidx = nidx.reshape(nidx.shape[0] if nidx.dim() == 5 else 1, -1, S + 1).expand(B, W, S + 1).contiguous()
+    if f64:
+        out = ops.TraceFunctionF64.apply(x_e, y_e, zv, cx2, cy2, c2, t2, mu3, kap, pol, mask_u8, kind_u8,
+                                         bool(allow_backward_rays), want_rays)
+        return _trace_result((*out, None, None), False, want_rays, False, False, True, P * W, B)
     out = ops.TraceFunction.apply(x_e, y_e, zv, cx2, cy2, c2, t2, mu3, kap, pol, mask_u8, kind_u8, nidx,
                                   bool(allow_backward_rays), mode or ops.get_default_mode(), want_rays, bool(want_opd),
                                   bool(aggregate), bool(aggregate is True and want_rays), bool(x_moments))
@@ -445,9 +461,9 @@ def compute_rms2d(x, y, ray_ok, group=None, n_per_field: Optional[int] = None):
         moments = tl_dist.all_reduce_sum(moments, group)
         if n_per_field is None:
             n_per_field = n_local * torch.distributed.get_world_size(group)
-    if moments.is_cuda:
+    if moments.is_cuda and y.dtype != torch.float64:
         return ops.spot_rms(moments, n_per_field or n_local).to(y.dtype)
-    return rms_from_moments(moments, n_per_field or n_local).to(y.dtype)
+    return rms_from_moments(moments, n_per_field or n_local).to(y.dtype)        # fp64 callers: the closed form in fp64
 
 
 def compute_rms2d_batch(x, y, ray_ok):
@@ -462,7 +478,7 @@ def compute_rms2d_batch(x, y, ray_ok):
         fold = lambda a: None if a is None else a.reshape(1, B * F, a.shape[2], a.shape[3])      # noqa: E731
         moments = ops.SpotMomentsFunction.apply(fold(x), fold(y), fold(ray_ok))
         n_local = y.shape[2] * y.shape[3]
-    if moments.is_cuda:
+    if moments.is_cuda and y.dtype != torch.float64:
         return ops.spot_rms(moments, n_local, B).reshape(B).to(y.dtype)
     m = moments.view(B, F, -1)
     mean = m[..., 0] / n_local
@@ -523,8 +539,6 @@ class RayTracer:
                     'skew_inner_square_half'):
             assert len(n_rays) == 2
         self.pupil_span = spans[mode]
-        if double_precision:
-            raise NotImplementedError("the HIP kernels compute in fp32; double_precision is not available")
         self.n_rays = n_rays
         self.rel_fields = rel_fields
         self.vig_fn = vig_fn
@@ -539,6 +553,10 @@ class RayTracer:
     def assemble(self, specs, lens, xy=None, up_to_stop=False, use_vig=True):
         """Everything `trace_skew` needs, as a dict: x, y, z, cx, cy, c, t, mu, mask."""
         dev = self.default_device
+        if self.double_precision and lens.c.dtype != torch.float64:
+            # ray_tracing_lite.py:82-84 (which crashes in the reference: its Specs / Lens have no .double()): everything
+            # downstream in fp64 -- dispersion, ABCD chain, fan, and the generic fp64 trace kernels (tl_trace_*_f64)
+            specs, lens = specs.double(), lens.double()
         n = lens.get_refractive_indices(self.wavelengths)                 # [1, S, W]
         n = torch.cat((torch.ones_like(n[:, :1, :]), n), dim=1).transpose(1, 2)
         n = n.reshape(n.shape[0], 1, 1, n.shape[1], -1)                   # [1,1,1,W,S+1]
