@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-other-mode", action="store_true", help="skip the secondary measurement of the other arithmetic mode")
     ap.add_argument("--no-also", action="store_true", help="skip the extra workloads reported next to the main one")
     ap.add_argument("--no-sweep", action="store_true", help="skip the rays x rows sweep")
+    ap.add_argument("--no-fp64-check", action="store_true", help="skip the full-size comparison with the double-precision kernels")
     ap.add_argument("--graph", action="store_true",
                     help="record one step (both kernels + reductions + closed form + autograd bookkeeping) into a HIP "
                          "graph and time replays of it instead of eager steps")
@@ -392,7 +393,7 @@ def main():
     head = summarize(job, times, a.steps)
     final_grads = grad_report(job, group, a.backend, device)
     fp64_full = None
-    if world == 1 and not a.graph:
+    if world == 1 and not a.graph and not a.no_fp64_check:
         try:
             job.step()                       # fresh fp32 gradients of one step
             fp64_full = full_size_fp64_check(job)

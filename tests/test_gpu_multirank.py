@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--steps", "3", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--no-other-mode", "--no-also",
-          "--no-sweep", "--no-graph-child"]
+          "--no-sweep", "--no-graph-child", "--no-fp64-check"]
 
 
 def _run(cmd, timeout=420):

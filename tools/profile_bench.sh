@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-other-mode --no-also --no-sweep --no-graph-child --repeats 1"
+B="python3 $R/bench.py --no-cpu-baseline --no-other-mode --no-also --no-sweep --no-graph-child --no-fp64-check --repeats 1"
 case $PASS in
   trace) rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 10 --warmup 2 "$@" > $OUT/trace.log 2>&1 ;;
   fetch) rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --steps 3 --warmup 1 "$@" > $OUT/pmc_fetch.log 2>&1 ;;
