@@ -270,3 +270,32 @@ def test_cfg4_total_on_one_gpu(ta):
     assert rel_l2(g_big.cpu().numpy(), leaves["c"].grad.cpu().numpy()) < 5e-3
     del x, y, cx, cy, ok, back
     torch.cuda.empty_cache()
+
+
+def test_forward_without_moments_clears_the_walk_back_flag_word(ta):
+    """a C-ABI caller that records tl_trace_fwd WITHOUT moments into a graph has no reduction kernel to clear
+    the walk-back's flag word between replays (a step replayed from a graph re-uses its token).  tl_trace_fwd given the full
+    tl_workspace_bytes(p) workspace clears the word itself in that case (tl_trace.h, tl_trace_bwd_from_outputs)."""
+    import ctypes as C
+    from torchoptics_amd import _lib, ops
+    from conftest import load_golden
+    g = load_golden("G4_tessar_32x32")
+    ins = [torch.from_numpy(g[n]).to(DEV) for n in ("in_x", "in_y", "in_z", "in_cx", "in_cy", "in_c", "in_t", "in_mu")]
+    mask = torch.from_numpy(g["in_mask"]).to(DEV)
+    F, P, W, S = ins[4].shape[1], ins[0].shape[2], ins[7].shape[3], ins[5].shape[-1]
+    x_e, y_e = ins[0].expand(1, F, P, W), ins[1].expand(1, F, P, W)
+    prob = ops._problem(x_e, y_e, ins[2].reshape(1), ins[3].reshape(1, -1), ins[4].reshape(1, -1).contiguous(),
+                        ins[5].reshape(1, S).contiguous(), ins[6].reshape(1, S).contiguous(), ins[7].reshape(1, W, S).contiguous(),
+                        mask.reshape(1, S).view(torch.uint8).contiguous(), True, "strict")
+    lib = _lib.lib()
+    n = lib.tl_workspace_bytes(C.byref(prob))
+    ws = torch.full((n,), 0xFF, dtype=torch.uint8, device=DEV)
+    outs = [torch.empty((1, F, W, P), dtype=torch.float32, device=DEV) for _ in range(4)]
+    flags = [torch.empty((1, F, W, P), dtype=torch.uint8, device=DEV) for _ in range(2)]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.tl_trace_fwd(C.byref(prob), *[_lib.ptr(o) for o in outs], *[_lib.ptr(f) for f in flags], None, None, None,
+                          _lib.ptr(ws), ws.numel(), st)
+    assert rc == 0, lib.tl_last_error()
+    torch.cuda.synchronize()
+    word = ws[n - 64:n - 60].cpu().numpy().view(np.uint32)[0]
+    assert word == 0 and ws[n - 68].item() == 0xFF and ws[n - 60].item() == 0xFF      # that word, and only it
