@@ -483,3 +483,36 @@ def test_launch_condition_gradients_on_the_two_asphere_double_gauss(ta, variant,
         print(f"cfg3a[{variant}] {algo} d/d{n}: vs fp64 {e64:.2e} (oracle fp32 itself {noise:.2e})")
         lim = max(3 * noise, 3e-5) if n in ("z", "cy") else 2e-5 + 2 * noise
         assert e64 <= lim, f"{algo} d/d{n}: {e64:.2e} vs oracle fp32 noise {noise:.2e}"
+
+
+@pytest.mark.parametrize("n_rays", [1000, 257, 300])
+@pytest.mark.parametrize("aggregate", [False, "sum"])
+def test_ragged_pupil_through_the_unrolled_aspheric_walk_back(ta, n_rays, aggregate):
+    """Pupils that do not fill their last 256-ray chunk (and the smallest ones the unrolled kernel takes): the walk-back over
+    stored hits -- with and without the penalty seed -- against the checkpoint algorithm on the same rays."""
+    from torchoptics_amd import ops, ray_tracing as rt
+    ins, mask = _inputs()
+    S = ins[5].shape[-1]
+    kap0, pol0, _ = asphere_params(S)
+    F, W = ins[4].shape[1], ins[7].shape[3]
+    x_in = ins[0][:, :, :n_rays].expand(1, F, n_rays, W).contiguous()
+    y_in = ins[1][:, :, :n_rays].expand(1, F, n_rays, W).contiguous()
+    grads = {}
+    for algo in ("inverse", "checkpoint"):
+        _algo(ops, algo)
+        try:
+            lv = [q.to(DEV).clone().requires_grad_(True) for q in (ins[2], ins[4], ins[5], ins[6], ins[7], kap0, pol0)]
+            out = ta.trace_skew(x_in.to(DEV), y_in.to(DEV), lv[0], ins[3].to(DEV), lv[1], lv[2], lv[3], lv[4], mask.to(DEV),
+                                aggregate, kappa=lv[5], poly=lv[6])
+            assert ops.used_walk_back(out[0]) is (algo == "inverse")
+            loss = ta.compute_rms2d(out[0], out[1], out[4])
+            if aggregate:
+                loss = loss + 0.2 * rt.penalty_sum(out[6], S)
+            loss.backward()
+            grads[algo] = [q.grad.cpu().numpy() for q in lv]
+        finally:
+            _algo_reset(ops)
+    for n, a, b in zip(("z", "cy", "c", "t", "mu", "kappa", "poly"), grads["inverse"], grads["checkpoint"]):
+        assert np.isfinite(a).all()
+        lim = (2e-3 if n in ("z", "cy") else 2e-4) if aggregate else (2e-4 if n in ("z", "cy") else 2e-5)
+        assert rel_l2(a, b) < lim, f"P={n_rays} aggregate={aggregate} d/d{n}: {rel_l2(a, b):.2e}"
