@@ -270,9 +270,9 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
                                      bool(aggregate), bool(aggregate is True and want_rays), bool(x_moments))
         n_pw = max(x.shape[2], y.shape[2]) * max(x.shape[3], y.shape[3], mu.shape[3])
         return _trace_result(out, use_inv, want_rays, want_opd, aggregate, x_moments, n_pw, B)
-    _as_f32 = _as_f64 if f64 else globals()["_as_f32"]          # (the normalisation below is dtype-blind)
-    x, y, z, cx, cy = (_as_f32(a, n) for a, n in ((x, 'x'), (y, 'y'), (z, 'z'), (cx, 'cx'), (cy, 'cy')))
-    c, t, mu = _as_f32(c, 'c'), _as_f32(t, 't'), _as_f32(mu, 'mu')
+    cast = _as_f64 if f64 else _as_f32          # (the normalisation below is dtype-blind)
+    x, y, z, cx, cy = (cast(a, n) for a, n in ((x, 'x'), (y, 'y'), (z, 'z'), (cx, 'cx'), (cy, 'cy')))
+    c, t, mu = cast(c, 'c'), cast(t, 't'), cast(mu, 'mu')
     for a, n in ((x, 'x'), (y, 'y'), (cx, 'cx'), (cy, 'cy'), (z, 'z')):
         if a.dim() != 4 or a.shape[0] not in (1, B):
             raise ValueError(f"{n} must be 4-D with 1 or {B} lenses in dim 0, got {tuple(a.shape)}")
@@ -299,9 +299,9 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
     kap = pol = kind_u8 = None
     if kappa is not None or poly is not None:
         # per lens [B,S] / [B,S,4], or one set [S] / [S,4] shared by every lens of the batch
-        kap = (_as_f32(kappa, 'kappa').reshape(-1, S) if kappa is not None
+        kap = (cast(kappa, 'kappa').reshape(-1, S) if kappa is not None
                else torch.zeros(1, S, device=c.device, dtype=c.dtype)).expand(B, S).contiguous()
-        pol = (_as_f32(poly, 'poly').reshape(-1, S, 4) if poly is not None
+        pol = (cast(poly, 'poly').reshape(-1, S, 4) if poly is not None
                else torch.zeros(1, S, 4, device=c.device, dtype=c.dtype)).expand(B, S, 4).contiguous()
         if surf_kind is None:
             surf_kind = (kap.detach() != 0) | (pol.detach() != 0).any(dim=-1)
@@ -310,7 +310,7 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
     if want_opd:
         if n_index is None:
             raise ValueError("want_opd=True needs n_index [1|B,1,1,W,S+1]")
-        nidx = _as_f32(n_index, 'n_index')
+        nidx = cast(n_index, 'n_index')
         nidx = nidx.reshape(nidx.shape[0] if nidx.dim() == 5 else 1, -1, S + 1).expand(B, W, S + 1).contiguous()
     if f64:
         out = ops.TraceFunctionF64.apply(x_e, y_e, zv, cx2, cy2, c2, t2, mu3, kap, pol, mask_u8, kind_u8,
