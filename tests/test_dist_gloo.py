@@ -118,3 +118,44 @@ def test_two_rank_sharded_loss_and_grads_equal_unsharded(tmp_path, monkeypatch, 
     # every rank ends with bitwise identical gradients (packed fp64 all-reduce)
     for g0, g1 in zip(res[0]["grads"], res[1]["grads"]):
         assert torch.equal(g0, g1)
+
+
+def test_spawn_local_ranks_starts_a_two_rank_job(tmp_path):
+    """dist.spawn_local_ranks (what `bench.py --gpus N` and `adam_loop.py --gpus N` use when no launcher is around): a child
+    torch.distributed.run with two ranks on 127.0.0.1, each joining through dist.init_group and summing its rank."""
+    import subprocess
+    script = tmp_path / "two_ranks.py"
+    script.write_text(
+        "import json, os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch\n"
+        "from torchoptics_amd import dist as tl_dist\n"
+        "group = tl_dist.init_group('cpu', 'gloo')\n"
+        "n = tl_dist.ranks_seen(group, 'cpu')\n"
+        "t = torch.tensor([float(os.environ['RANK']) + 1.0], dtype=torch.float64)\n"
+        "s = tl_dist.all_reduce_sum(t, group)\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    print(json.dumps(dict(n=n, s=float(s), world=int(os.environ['WORLD_SIZE']))))\n"
+        "torch.distributed.destroy_process_group()\n")
+    driver = tmp_path / "driver.py"
+    driver.write_text(
+        "import sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from torchoptics_amd import dist as tl_dist\n"
+        f"raise SystemExit(tl_dist.spawn_local_ranks({str(script)!r}, [], 2, timeout=240))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cp = subprocess.run([sys.executable, str(driver)], capture_output=True, text=True, timeout=300, env=env)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    import json
+    line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out == dict(n=2, s=3.0, world=2)
+
+
+def test_init_group_refuses_many_ranks_without_a_port(monkeypatch):
+    from torchoptics_amd import dist as tl_dist
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        tl_dist.init_group("cpu", "gloo")
