@@ -94,6 +94,14 @@ typedef struct tl_problem {
     int32_t asph_hit_slots;      /* 0..TL_MAX_HIT_SLOTS */
     int32_t moments_x;           /* 1: tl_trace_fwd also accumulates the x-moments 4..6 (compute_rms2d reads y only:
                                     ray_tracing_lite.py:684-701); 0: they are returned as 0 */
+    uint8_t *cond_flags;         /* [B,F,W,P] bytes, nullable: the `ok` output with the conditioning flag -- 0 dead, 1 live, 2 live
+                                    and ill-conditioned (smallest cos^2 of incidence or refraction below 0.01: the rays moment 9
+                                    counts) -- WRITTEN by tl_trace_fwd (next to `ok`, which stays 0/1), READ by
+                                    tl_trace_bwd_from_outputs in place of ok_fwd.  With it, a launch that holds such rays is
+                                    no longer handed to the checkpoint kernel as a whole: the walk-back differentiates the
+                                    rays marked 1 and the checkpoint kernel exactly those marked 2 (waves without one skip
+                                    their chunk); the two partial sums are added.  NULL: one ill-conditioned ray sends the
+                                    whole launch to the checkpoint kernel. */
 } tl_problem;
 
 int         tl_version(void);            /* == TL_ABI_VERSION */

@@ -306,8 +306,8 @@ def test_penalty_term_on_aspheric_rows(ta, mode):
 def test_conditioning_count_covers_aspheric_and_opd_rows(ta):
     """moment 9 (ill-conditioned live rays) was only updated by plain spherical rows, so a grazing
     fan on a lens with Newton rows was walked back unguarded.  Fixture G5 (grazing, failure-heavy) with every row
-    but the stop traced as a zero-coefficient Newton row: the forward must count ill-conditioned rays, and the
-    default backward must therefore equal the checkpoint algorithm bit for bit."""
+    but the stop traced as a zero-coefficient Newton row: the forward must count (and flag) ill-conditioned rays, so
+    that the default backward hands them to the checkpoint kernel and stays within 1e-5 of it."""
     from torchoptics_amd import ops
     ins, mask = _inputs("G5_cooke_failures")
     S = ins[5].shape[-1]
@@ -327,7 +327,7 @@ def test_conditioning_count_covers_aspheric_and_opd_rows(ta):
         finally:
             ops.set_backward_algorithm("inverse")
     for a, b in zip(grads["inverse"], grads["checkpoint"]):
-        assert torch.equal(a, b)
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
 
 
 def test_more_aspheric_rows_than_hit_slots_fall_back_on_the_device(ta):

@@ -398,7 +398,8 @@ def test_checkpoint_free_backward_with_dense_upstream_gradients(ta):
 def test_conditioning_count_selects_the_backward_kernel_on_the_device(ta):
     """Moment 9 = number of live rays with min cos^2 < 0.01 along their path.  Zero for every sane fan (the
     walk-back kernel then does the backward); non-zero for the failure-heavy fixture, where the checkpoint
-    kernel takes over inside the same call, so that gradients stay within 1e-5 of autograd there too."""
+    kernel takes those rays inside the same call (the forward flags them per ray: test_gpu_conditioning.py), so that
+    gradients stay within 1e-5 of autograd there too."""
     counts = {}
     for case in ("G2_cooke_16x16", "G4_tessar_32x32", "G5_cooke_failures"):
         g = load_golden(case)
@@ -407,7 +408,7 @@ def test_conditioning_count_selects_the_backward_kernel_on_the_device(ta):
         counts[case] = y._tl_spot[0][:, 9].sum().item()
     assert counts["G2_cooke_16x16"] == 0 and counts["G4_tessar_32x32"] == 0
     assert counts["G5_cooke_failures"] > 0
-    # and the fallback really is bit-identical to calling the checkpoint algorithm directly
+    # and the split result is the checkpoint algorithm's up to the walk-back's rounding on the well-conditioned rays
     from torchoptics_amd import ops
     g = load_golden("G5_cooke_failures")
     grads = {}
@@ -422,7 +423,7 @@ def test_conditioning_count_selects_the_backward_kernel_on_the_device(ta):
         finally:
             ops.set_backward_algorithm("inverse")
     for a, b in zip(grads["inverse"], grads["checkpoint"]):
-        assert torch.equal(a, b)
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
 
 
 def test_walk_back_non_finite_adjoint_falls_back_to_checkpoint_kernel(ta):

@@ -182,7 +182,7 @@ def test_cabi_library_exports_every_declared_symbol():
     p = _lib.tl_problem()
     p.F, p.P, p.W, p.S = 3, 1 << 20, 3, 7
     assert dll.tl_workspace_bytes(ctypes.byref(p)) > 0
-    assert ctypes.sizeof(_lib.tl_problem) == dll.tl_problem_size() == 240
+    assert ctypes.sizeof(_lib.tl_problem) == dll.tl_problem_size() == 248
 
 
 def test_gradient_free_conversions_are_memoised_safely():

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--asph-zero", action="store_true",
                     help="all-spherical workload through the ASPHERIC kernel variants: kappa = poly = 0 and no row marked "
                          "aspheric (what the variants cost on spherical rows)")
+    ap.add_argument("--cond-flags", action="store_true", help="hand the forward a tl_problem.cond_flags buffer (what the host chains do)")
     a = ap.parse_args()
     import bench
     from torchoptics_amd import _lib, ops
@@ -57,9 +58,11 @@ def main():
         kind = ((kap != 0) | (pol != 0).any(dim=1)).to(torch.uint8).contiguous()
         if a.hit_slots:
             hits = torch.empty((a.hit_slots, 2, 1, F, W, P), dtype=torch.float32, device=dev)
+    cond = torch.empty((1, F, W, P), dtype=torch.uint8, device=dev) if a.cond_flags else None      # (must outlive prob)
     prob = ops._problem(x_e, y_e, args["z"].detach().reshape(1).contiguous(), cxv, cyv,
                         args["c"].detach().reshape(S).contiguous(), args["t"].detach().reshape(S).contiguous(),
-                        mu2, mask, True, a.mode, kap, pol, kind, None, a.aggregate, hits)
+                        mu2, mask, True, a.mode, kap, pol, kind, None, a.aggregate, hits,
+                        cond=cond)
     outs = [torch.empty((1, F, W, P), dtype=torch.float32, device=dev) for _ in range(4)]
     flags = [torch.empty((1, F, W, P), dtype=torch.uint8, device=dev) for _ in range(2)]
     mom = torch.empty((F, _lib.TL_NMOM), dtype=torch.float64, device=dev)

@@ -33,7 +33,7 @@ class tl_problem(C.Structure):
         ("kappa", C.c_void_p), ("poly", C.c_void_p), ("surf_kind", C.c_void_p), ("n_index", C.c_void_p),
         ("B", C.c_int32), ("cx_stride_b", C.c_int32), ("cy_stride_b", C.c_int32),
         ("xs_b", C.c_int64), ("ys_b", C.c_int64),
-        ("asph_hits", C.c_void_p), ("asph_hit_slots", C.c_int32), ("moments_x", C.c_int32),
+        ("asph_hits", C.c_void_p), ("asph_hit_slots", C.c_int32), ("moments_x", C.c_int32), ("cond_flags", C.c_void_p),
     ]
 
 

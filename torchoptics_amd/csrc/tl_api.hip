@@ -161,9 +161,11 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
         double n = 0.0;
         if (fmom)
             for (int f = 0; f < F * (int)gridDim.y; ++f) n += fmom[(size_t)f * TL_NMOM + 9];
-        if (n > 0.0 || (poison && *poison == token)) {
+        // add_alt bit 1: the forward left per-ray conditioning flags (tl_problem.cond_flags), so ill-conditioned rays
+        // (n > 0) were split between the two launches as well, instead of sending the whole launch to the checkpoint kernel
+        if ((n > 0.0 && !(add_alt & 2)) || (poison && *poison == token)) {
             part = alt_part; NS = alt_NS; ncol = tl_bwd_row(alt_NS, g_kappa != nullptr); nbx = alt_nbx;
-        } else if (add_alt) {
+        } else if ((add_alt & 1) || n > 0.0) {
             part2 = alt_part; NS2 = alt_NS; nbx2 = alt_nbx;
         }
     }
@@ -648,6 +650,8 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     int rc = check_problem(p);
     if (rc) return rc;
     if (!g_c || !g_t || !g_mu || !g_z || !g_cx || !g_cy) return fail(TL_EINVAL, "a parameter-gradient output is NULL");
+    // p->cond_flags (written by the forward) is the ok bytes with the conditioning flag: it is read instead of ok_fwd
+    if (p->cond_flags) ok_fwd = p->cond_flags;
     if (p->P > 0 && (!x_fwd || !y_fwd || !cx_fwd || !cy_fwd || !ok_fwd))
         return fail(TL_EINVAL, "the forward outputs x, y, cx, cy, ok are required");
     if (!p->allow_backward)
@@ -690,7 +694,8 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     const int nout = 2 * p->S + p->W * p->S + 1 + 2 * p->F + (asph ? 5 * p->S : 0);
     hipLaunchKernelGGL(reduce_bwd_kernel, dim3(nout, lenses(p)), dim3(kBlock), 0, st, part, p->S, p->F, p->W, p->S, pl.nbx, g_c, g_t,
                        g_mu, g_z, g_cx, g_cy, ncol, g_kappa, g_poly, (const double *)part_ck, ns,
-                       moments_fwd, (const unsigned *)poison, token, pk.nbx, (float *)nullptr, p->aggregate ? 1 : 0);
+                       moments_fwd, (const unsigned *)poison, token, pk.nbx, (float *)nullptr,
+                       (p->aggregate ? 1 : 0) | (p->cond_flags ? 2 : 0));
     herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "reduce_bwd_kernel launch");
     return TL_OK;

@@ -127,7 +127,7 @@ struct Norm {                       // trace_skew's arguments brought to the ker
 const void *ptr(const Tensor &t) { return t.defined() ? t.data_ptr() : nullptr; }
 
 tl_problem make_problem(const Norm &n, bool allow_back, int mode, bool aggregate, const Tensor &hits, bool moments_x,
-                        bool with_n_index)
+                        bool with_n_index, const Tensor &cond)
 {
     tl_problem p{};
     p.F = (int32_t)n.F; p.P = (int32_t)n.P; p.W = (int32_t)n.W; p.S = (int32_t)n.S; p.B = (int32_t)n.B;
@@ -152,6 +152,7 @@ tl_problem make_problem(const Norm &n, bool allow_back, int mode, bool aggregate
     p.asph_hits = hits.defined() ? (float *)hits.data_ptr() : nullptr;
     p.asph_hit_slots = hits.defined() ? (int32_t)hits.size(0) : 0;
     p.moments_x = moments_x ? 1 : 0;
+    p.cond_flags = cond.defined() ? (uint8_t *)cond.data_ptr() : nullptr;
     return p;
 }
 
@@ -259,7 +260,10 @@ public:
         Tensor hits;
         if (use_inv && asph && hit_slots > 0 && need_any)
             hits = at::empty({std::min<int64_t>(hit_slots, S), 2, B, F, W, P}, fopt);
-        tl_problem prob = make_problem(n, allow_back, (int)mode, aggregate, hits, moments_x, want_opd);
+        // one byte per ray: the ill-conditioned live rays, which the backward then leaves to the checkpoint kernel (ops.py)
+        Tensor cond;
+        if (use_inv && need_any) cond = at::empty({B, F, W, P}, fopt.dtype(at::kByte));
+        tl_problem prob = make_problem(n, allow_back, (int)mode, aggregate, hits, moments_x, want_opd, cond);
         const size_t nbytes = tl_workspace_bytes(&prob);
         Tensor ws = workspace(nbytes, dev, (void *)st);
         Tensor fp[4], bp[2], opd, stacks;
@@ -280,7 +284,7 @@ public:
         const bool inv = use_inv;
         ctx->save_for_backward({n.x_e, n.y_e, n.z, n.cx, n.cy, n.c, n.t, n.mu, n.mask, n.kappa, n.poly, n.kind,
                                 inv ? fp[0] : Tensor(), inv ? fp[1] : Tensor(), inv ? fp[2] : Tensor(), inv ? fp[3] : Tensor(),
-                                inv ? bp[0] : Tensor(), inv ? moments : Tensor(), want_opd ? n.n_index : Tensor(), hits});
+                                inv ? bp[0] : Tensor(), inv ? moments : Tensor(), want_opd ? n.n_index : Tensor(), hits, cond});
         // needs_input_grad() of the backward counts the tensor arguments that are PRESENT: an absent optional has no edge
         {
             int64_t e = 9;
@@ -325,7 +329,7 @@ public:
         n.mask = sv[8]; n.kappa = sv[9]; n.poly = sv[10]; n.kind = sv[11];
         const Tensor fx = sv[12], fy = sv[13], fcx = sv[14], fcy = sv[15], fok = sv[16], fmom = sv[17];
         n.n_index = sv[18];
-        const Tensor hits = sv[19];
+        const Tensor hits = sv[19], cond = sv[20];
         n.B = n.x_e.size(0); n.F = n.x_e.size(1); n.P = n.x_e.size(2); n.W = n.x_e.size(3); n.S = n.c.size(-1);
         const int64_t B = n.B, F = n.F, P = n.P, W = n.W, S = n.S;
         const int64_t flags = ctx->saved_data["flags"].toInt();
@@ -340,7 +344,7 @@ public:
         c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
         const hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
         tl_problem prob = make_problem(n, allow_back, (int)ctx->saved_data["mode"].toInt(), aggregate, hits, false,
-                                       gopd.defined());
+                                       gopd.defined(), cond);
         Tensor ws = workspace(tl_workspace_bytes(&prob), dev, (void *)st);
         auto fwp = [](const Tensor &t) {               // [B,F,P,W] logical -> memory [B,F,W,P] contiguous
             if (!t.defined() || t.numel() == 0) return Tensor();

@@ -193,7 +193,7 @@ def set_asph_hit_slots(n: int) -> None:
 
 
 def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa=None, poly=None, kind_u8=None,
-             n_index=None, aggregate=False, hits=None, moments_x=False):
+             n_index=None, aggregate=False, hits=None, moments_x=False, cond=None):
     B, F, P, W = x_e.shape
     p = tl_problem()
     p.F, p.P, p.W, p.S = F, P, W, c.shape[-1]
@@ -220,6 +220,7 @@ def _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa=Non
     p.asph_hits = hits.data_ptr() if hits is not None else None
     p.asph_hit_slots = hits.shape[0] if hits is not None else 0
     p.moments_x = 1 if moments_x else 0
+    p.cond_flags = cond.data_ptr() if cond is not None else None
     return p
 
 
@@ -256,8 +257,12 @@ class TraceFunction(torch.autograd.Function):
         hits = None
         if use_inv and kind_u8 is not None and ASPH_HIT_SLOTS > 0 and any(ctx.needs_input_grad[2:10]):
             hits = torch.empty((min(ASPH_HIT_SLOTS, S), 2, B, F, W, P), dtype=torch.float32, device=dev)
+        # one byte per ray: the forward flags the ill-conditioned live rays, so that the backward can leave exactly those
+        # to the checkpoint kernel and walk back the rest (without it, one such ray costs the whole launch the walk-back)
+        cond = (torch.empty((B, F, W, P), dtype=torch.uint8, device=dev)
+                if use_inv and any(ctx.needs_input_grad[2:10]) else None)
         prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, allow_back, mode, kappa, poly, kind_u8, n_index, aggregate,
-                        hits, moments_x)
+                        hits, moments_x, cond)
         nbytes = lib.tl_workspace_bytes(C.byref(prob))
         ws = _workspace(nbytes, dev)
         if want_rays:
@@ -277,7 +282,7 @@ class TraceFunction(torch.autograd.Function):
         _last_use_inv = use_inv
         fwd_out = (fp[0], fp[1], fp[2], fp[3], bp[0], moments) if use_inv else (None,) * 6
         ctx.save_for_backward(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, *fwd_out,
-                              n_index if want_opd else None, hits)
+                              n_index if want_opd else None, hits, cond)
         ctx.allow_back, ctx.mode, ctx.aggregate, ctx.use_inv = allow_back, mode, aggregate, use_inv
         ctx.prob, ctx.ws_bytes = prob, nbytes      # same tensors, same pointers in backward: no need to fill it again
         ctx.set_materialize_grads(False)
@@ -297,7 +302,7 @@ class TraceFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gx, gy, gcx, gcy, _gok, _gback, gmom, gopd, _gstk):
         (x_e, y_e, z, cx, cy, c, t, mu, mask_u8, kappa, poly, kind_u8, fx, fy, fcx, fcy, fok, fmom,
-         n_index, hits) = ctx.saved_tensors
+         n_index, hits, cond) = ctx.saved_tensors
         dev = x_e.device
         B, F, P, W = x_e.shape
         S = c.shape[-1]
@@ -311,9 +316,10 @@ class TraceFunction(torch.autograd.Function):
         prob = ctx.prob
         # saved-tensor hooks (save_on_cpu, checkpointing) hand back tensors in other storage than the forward saw
         if (prob.x_in != (x_e.data_ptr() or None) or prob.c != c.data_ptr() or prob.mu != mu.data_ptr()
-                or prob.asph_hits != (hits.data_ptr() if hits is not None else None)):
+                or prob.asph_hits != (hits.data_ptr() if hits is not None else None)
+                or prob.cond_flags != (cond.data_ptr() if cond is not None else None)):
             prob = _problem(x_e, y_e, z, cx, cy, c, t, mu, mask_u8, ctx.allow_back, ctx.mode, kappa, poly, kind_u8, None,
-                            ctx.aggregate, hits, False)
+                            ctx.aggregate, hits, False, cond)
         prob.n_index = n_index.data_ptr() if gopd is not None else None
         ws = _workspace(ctx.ws_bytes, dev)
 
