@@ -61,8 +61,8 @@ def test_pupil_position_feeds_trace_rays_and_the_adam_step():
         c, t = leaves["c"].detach().clone().requires_grad_(True), leaves["t"].detach().clone().requires_grad_(True)
         lens = ta.Lens(lens0.structure, c, t, leaves["nd"].detach(), leaves["v"].detach())
         if tag == "chain":
-            def chain(lz, mode=None):
-                front = lz.up_to_stop()
+            def chain(lz, mode=None, front=None):
+                front = lz.up_to_stop() if front is None else front
                 m = paraxial.reduce_abcd(paraxial.interface_propagation_abcd(front.c, front.t,
                                                                             paraxial._with_air_in_front(front.nd)))
                 return m[:, 0, 1] / m[:, 0, 0]

@@ -436,6 +436,54 @@ public:
     }
 };
 
+// z [B] = paraxial entrance-pupil position of the rows in front of the stop (tl_pupil_position forward / backward): the
+// counterpart of ops.PupilPositionFunction
+class PupilPositionFn : public torch::autograd::Function<PupilPositionFn> {
+public:
+    static Tensor forward(AutogradContext *ctx, const Tensor &c_in, const Tensor &t_in, const Tensor &n_in, int64_t mode)
+    {
+        require_device(c_in, "c"); require_device(t_in, "t"); require_device(n_in, "n");
+        TORCH_CHECK(c_in.dim() == 2, "pupil position: c must be [B,K]");
+        const int64_t B = c_in.size(0), K = c_in.size(1);
+        TORCH_CHECK(t_in.dim() == 2 && t_in.size(0) == B && t_in.size(1) == K && n_in.dim() == 2 && n_in.size(0) == B &&
+                        n_in.size(1) == K + 1,
+                    "pupil position: c, t must hold [B,K] rows and n [B,K+1] indices");
+        const Tensor c = dense(f32(c_in.detach())), t = dense(f32(t_in.detach())), n = dense(f32(n_in.detach()));
+        const at::Device dev = c.device();
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+        const hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
+        Tensor z = at::empty({B}, c.options());
+        check(tl_pupil_position(dev.index(), (int32_t)B, (int32_t)K, (const float *)c.data_ptr(), (const float *)t.data_ptr(),
+                                (const float *)n.data_ptr(), (float *)z.data_ptr(), nullptr, nullptr, nullptr, nullptr,
+                                (int32_t)mode, (void *)st),
+              "tl_pupil_position");
+        ctx->save_for_backward({c, t, n});
+        ctx->saved_data["mode"] = mode;
+        return z;
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list g)
+    {
+        if (!g[0].defined()) return {Tensor(), Tensor(), Tensor(), Tensor()};
+        const auto sv = ctx->get_saved_variables();
+        const Tensor c = sv[0], t = sv[1], n = sv[2];
+        const int64_t B = c.size(0), K = c.size(1);
+        const Tensor gz = dense(f32(g[0]).reshape({B}));
+        const at::Device dev = c.device();
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+        const hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
+        Tensor g_c = at::empty_like(c), g_t = at::empty_like(t), g_n = at::empty_like(n);
+        check(tl_pupil_position(dev.index(), (int32_t)B, (int32_t)K, (const float *)c.data_ptr(), (const float *)t.data_ptr(),
+                                (const float *)n.data_ptr(), nullptr, (const float *)gz.data_ptr(), (float *)g_c.data_ptr(),
+                                (float *)g_t.data_ptr(), (float *)g_n.data_ptr(), (int32_t)ctx->saved_data["mode"].toInt(),
+                                (void *)st),
+              "tl_pupil_position (backward)");
+        return {g_c, g_t, g_n, Tensor()};
+    }
+};
+
+Tensor pupil_position(const Tensor &c, const Tensor &t, const Tensor &n, int64_t mode) { return PupilPositionFn::apply(c, t, n, mode); }
+
 std::vector<Tensor> trace(const Tensor &x, const Tensor &y, const Tensor &z, const Tensor &cx, const Tensor &cy, const Tensor &c,
                           const Tensor &t, const Tensor &mu, const Tensor &mask, const c10::optional<Tensor> &kappa,
                           const c10::optional<Tensor> &poly, const c10::optional<Tensor> &kind,
@@ -456,6 +504,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.doc() = "C++ autograd wrappers of libtltrace.so's C ABI (the eager host chain of torchoptics_amd)";
     m.def("trace", &trace);
     m.def("spot_rms", &spot_rms);
+    m.def("pupil_position", &pupil_position);
     m.def("last_use_inv", [] { return g_last_use_inv; });
     m.def("enable_timing", &enable_timing);
     m.def("timing_ms", &timing_ms);

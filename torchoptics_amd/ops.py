@@ -575,6 +575,14 @@ def trace_cpp(ext, x, y, z, cx, cy, c, t, mu, mask, kappa, poly, kind, n_index, 
     return out, ext.last_use_inv()
 
 
+def pupil_position(c, t, n, mode=None):
+    """PupilPositionFunction, through the C++ host extension when it is there."""
+    ext = _ext()
+    if ext is not None and c.is_cuda and hasattr(ext, "pupil_position"):
+        return ext.pupil_position(c, t, n, _MODES[mode or _default_mode])
+    return PupilPositionFunction.apply(c, t, n, mode)
+
+
 def spot_rms(moments, n_per_field, n_lens=1):
     """compute_rms2d on the moments (SpotRmsFunction), through the C++ host extension when it is there."""
     ext = _ext()

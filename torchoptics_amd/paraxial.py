@@ -41,19 +41,21 @@ def _with_air_in_front(nd: torch.Tensor) -> torch.Tensor:
     return torch.cat((torch.ones_like(nd[:, :1]), nd), dim=1)
 
 
-def compute_pupil_position(lens: Lens, mode=None) -> torch.Tensor:
+def compute_pupil_position(lens: Lens, mode=None, front: Lens = None) -> torch.Tensor:
     """Paraxial entrance-pupil position w.r.t. the first vertex: B/A of the rows before the stop.
     `mode` (GPU only): 'strict' = the reference's fp32 value bit for bit, 'fast' = fp64 inside, rounded once;
-    default ops.get_default_mode()."""
-    front = lens.up_to_stop()
+    default ops.get_default_mode().  `front`: lens.up_to_stop() if the caller has it already."""
+    if front is None:
+        front = lens.up_to_stop()
     if front.structure.mask.shape[1] == 0:
         return torch.zeros(len(front), dtype=lens.c.dtype, device=lens.c.device)
-    n = _with_air_in_front(front.nd)
+    from .lens_modeling import _memoised
+    n = _memoised("n_front", (), (front.nd,), (front.nd,), lambda: _with_air_in_front(front.nd))     # constant glasses: once
     if front.c.is_cuda and front.c.dtype == torch.float32:
         # on the GPU (the hot configuration): the whole chain below and its autograd backward are one tiny kernel
         # each (tl_pupil_position, one thread per lens, fp64 inside) instead of ~25 + ~60 launches
         from . import ops
-        return ops.PupilPositionFunction.apply(front.c, front.t, n, mode).to(lens.c.dtype)
+        return ops.pupil_position(front.c, front.t, n, mode).to(lens.c.dtype)
     m = reduce_abcd(interface_propagation_abcd(front.c, front.t, n))
     return m[:, 0, 1] / m[:, 0, 0]
 

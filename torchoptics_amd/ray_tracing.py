@@ -181,6 +181,10 @@ def apply_vignetting(y, vig_up, vig_down):
 
 def scale_to_epd(y, epd):
     """Relative pupil coordinate -> height at the pupil plane: y * epd / 2."""
+    if y.dim() == 4 and not epd.requires_grad:
+        # (y epd) / 2 == y (epd / 2) bit for bit (a power of two); epd / 2 is the same tensor every step
+        from .lens_modeling import _memoised
+        return y * _memoised("epd_half", (), (epd,), (epd,), lambda: epd.reshape(-1, 1, 1, 1) / 2)
     return y * epd.reshape(-1, *([1] * (y.dim() - 1))) / 2
 
 
@@ -386,8 +390,15 @@ class PenaltyStacks(dict):
         if stk is not None:        # aggregate='sum': the fused sums only, no per-surface tensors (132 B per ray at 11 rows)
             for j, key in enumerate(('z_RELU', 'theta_norm', 'theta_prime_norm')):
                 self[key] = list(torch.unbind(stk[j], dim=0))
-        self.q_sum = moments[:, 8].sum()
-        self.q_per_lens = moments[:, 8].view(n_lens, -1).sum(dim=1)      # lens batch: one penalty sum per lens
+        self._moments, self._n_lens = moments, n_lens
+
+    @property
+    def q_sum(self):
+        return self._moments[:, 8].sum()
+
+    @property
+    def q_per_lens(self):                    # lens batch: one penalty sum per lens
+        return self._moments[:, 8].view(self._n_lens, -1).sum(dim=1)
 
 
 def penalty_sum(stacks, n_sequence: int):
@@ -557,28 +568,39 @@ class RayTracer:
             # ray_tracing_lite.py:82-84 (which crashes in the reference: its Specs / Lens have no .double()): everything
             # downstream in fp64 -- dispersion, ABCD chain, fan, and the generic fp64 trace kernels (tl_trace_*_f64)
             specs, lens = specs.double(), lens.double()
-        n = lens.get_refractive_indices(self.wavelengths)                 # [1, S, W]
-        n = torch.cat((torch.ones_like(n[:, :1, :]), n), dim=1).transpose(1, 2)
-        n = n.reshape(n.shape[0], 1, 1, n.shape[1], -1)                   # [1,1,1,W,S+1]
+        from .lens_modeling import _memoised
+        n_rows = lens.get_refractive_indices(self.wavelengths)            # [1, S, W]
+
+        def with_object_space():
+            m = torch.cat((torch.ones_like(n_rows[:, :1, :]), n_rows), dim=1).transpose(1, 2)
+            return m.reshape(m.shape[0], 1, 1, m.shape[1], -1)            # [1,1,1,W,S+1]
+        # (constant glasses: the dispersion result is the same tensor every step, and so is everything derived from it)
+        n = _memoised("n_index", (), (n_rows,), (n_rows,), with_object_space)
         strict = (self.arith or ops.get_default_mode()) == "strict"
-        z = compute_pupil_position(lens, self.arith).reshape(-1, 1, 1, 1)
+        # the rows in front of the stop are cut out once: the pupil position and the ray aiming both start from them
+        # (each Lens built on the way is ~10 tiny host-side view ops; this chain is what bounds a small minibatch)
+        front = lens.up_to_stop()
+        z1 = compute_pupil_position(lens, self.arith, front=front)
+        z = z1.reshape(-1, 1, 1, 1)
         xp_rel, yp_rel = self.pupil_span(z) if xy is None else xy
         if use_vig and self.vig_fn is not None and self.mode != 'chief':
             yp_rel, xp_rel = self._vignette(specs, yp_rel.to(dev), xp_rel.to(dev))
         if self.n_ray_aiming_iter > 0 and not up_to_stop:
-            aim = self.ray_aiming(specs, lens.detach(), use_vig)
+            aim = self.ray_aiming(specs, lens, use_vig, front=front, z=z1.detach())
             xp_rel, yp_rel = (torch.clamp(v, -2, 2).to(dev).detach() for v in aim(xp_rel, yp_rel))
         from .lens_modeling import const_tensor
         fields = const_tensor(list(self.rel_fields), torch.float32, dev)
-        ang = (specs.hfov[:, None] * fields[None, :])[..., None, None]
         # strict: the correctly rounded fp32 sine (evaluated in fp64, rounded once) -- the reference's value on every CPU
         # whose libm rounds correctly there, and the fixtures' bit for bit; fast: the device's fp32 sine
-        cy = torch.sin(ang.double()).to(ang.dtype) if (strict and ang.is_cuda and ang.dtype == torch.float32) else torch.sin(ang)
+        def sines():
+            ang = (specs.hfov[:, None] * fields[None, :])[..., None, None]
+            return torch.sin(ang.double()).to(ang.dtype) if (strict and ang.is_cuda and ang.dtype == torch.float32) else torch.sin(ang)
+        cy = _memoised("cy", (strict,), (specs.hfov, fields), (specs.hfov,), sines)
         cx = const_tensor([0.0], torch.float32, dev, (1, 1, 1, 1))
         out = dict(
             x=scale_to_epd(xp_rel.to(dev), specs.epd), y=scale_to_epd(yp_rel.to(dev), specs.epd), z=z, cx=cx, cy=cy,
             c=lens.c.reshape(lens.c.shape[0], 1, 1, 1, -1), t=lens.t.reshape(lens.t.shape[0], 1, 1, 1, -1),
-            mu=n[..., :-1] / n[..., 1:],
+            mu=_memoised("mu", (), (n,), (n,), lambda: n[..., :-1] / n[..., 1:]),
             mask=lens.structure.mask_torch.reshape(lens.c.shape[0], 1, 1, 1, -1))
         if getattr(lens, "kappa", None) is not None:        # aspheric extension of Lens (not in the reference)
             out.update(kappa=lens.kappa, poly=lens.poly, n_index=n)
@@ -609,7 +631,7 @@ class RayTracer:
         return trace_skew(a['x'], a['y'], a['z'], a['cx'], a['cy'], a['c'], a['t'], a['mu'], a['mask'],
                           aggregate, self.allow_backward_rays, mode=self.arith, **extra)
 
-    def _ray_aiming_kernel(self, specs2stop, lens2stop):
+    def _ray_aiming_kernel(self, specs2stop, lens2stop, z=None):
         """ray_aiming as ONE kernel (tl_ray_aim): marginal ray, the three tee rays with their Jacobian, the Newton step
         and the affine pupil map, per (lens, field, wavelength) in fp64 registers -- instead of two eager traces, an
         autograd pass and ~60 tensor ops (1.1 ms of host time per call for a 256-lens minibatch, 0.1 ms now)."""
@@ -619,9 +641,11 @@ class RayTracer:
         dev = lens2stop.c.device
         B, K = lens2stop.c.shape
         F, W = len(self.rel_fields), len(self.wavelengths)
-        n = _dense(lens2stop.get_refractive_indices(self.wavelengths).detach())            # [B,K,W]
-        n_d = _dense(lens2stop.get_refractive_indices([_LINES['d']]).detach())             # [B,K,1]
-        z = _dense(compute_pupil_position(lens2stop, self.arith).detach())
+        with torch.no_grad():              # (lens2stop may still be attached to the caller's graph: values only here)
+            n = _dense(lens2stop.get_refractive_indices(self.wavelengths).detach())            # [B,K,W]
+            n_d = _dense(lens2stop.get_refractive_indices([_LINES['d']]).detach())             # [B,K,1]
+            # (z: the pupil position of these rows when the caller has it -- up_to_stop of the cut lens is the cut lens)
+            z = _dense((compute_pupil_position(lens2stop, self.arith) if z is None else z).detach())
         c, t = _dense(lens2stop.c.detach()), _dense(lens2stop.t.detach())
         mask = _dense(lens2stop.structure.mask_torch.view(torch.uint8))
         kap = pol = kind = None
@@ -644,18 +668,22 @@ class RayTracer:
         return remap
 
     # -- ray aiming (ray_tracing_lite.py:129-208) ---------------------------------------------
-    def ray_aiming(self, specs, lens, use_vig):
+    def ray_aiming(self, specs, lens, use_vig, front=None, z=None):
         """One Newton step per iteration on the pupil coordinates of three 'tee' rays so that
         they land on the stop where an ideal pupil would put them; returns the affine pupil
-        remap.  The Jacobian diagonal comes from the backward kernel's per-ray input grads."""
+        remap.  The Jacobian diagonal comes from the backward kernel's per-ray input grads.
+        `front`, `z`: lens.up_to_stop() and its pupil position [B] if the caller has them already (`lens` and `front`
+        may then still be attached to a graph: nothing here differentiates through them)."""
         if (lens.structure.stop_idx == 0).all():
             return lambda xp_rel, yp_rel: (xp_rel, yp_rel)
         if self.n_ray_aiming_iter > 1:
             raise NotImplementedError("n_ray_aiming_iter >= 2 fails in the reference as well (Appendix B4)")
-        specs2stop, lens2stop = specs.up_to_stop(), lens.up_to_stop()
+        specs2stop, lens2stop = specs.up_to_stop(), (lens.up_to_stop() if front is None else front)
         if (self.ray_aiming_mode == 'real' and lens2stop.c.is_cuda and lens2stop.c.dtype == torch.float32
                 and not (use_vig and self.vig_fn is not None) and _AIM_KERNEL):
-            return self._ray_aiming_kernel(specs2stop, lens2stop)
+            return self._ray_aiming_kernel(specs2stop, lens2stop, z)
+        if front is not None:
+            lens2stop = lens2stop.detach()
         if self.ray_aiming_mode == 'paraxial':
             rs = (compute_magnification(lens2stop) * specs2stop.epd / 2).reshape(-1, 1, 1, 1)
         elif self.ray_aiming_mode == 'real':
