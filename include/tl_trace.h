@@ -219,6 +219,23 @@ int tl_spot_moments(int32_t device, int32_t F, int32_t P, int32_t W,
 int tl_spot_rms(int32_t device, int32_t B, int32_t F, double n_per_field, const double *moments, float *rms,
                 double *d_moments, void *stream);
 
+/*
+ * loss_dict of RaytracedOptics.compute_loss_out (optics_simulator_lite.py:430-450) per lens, on the moments of an
+ * aggregate trace:  rms[b] as tl_spot_rms,  penalty[b] = (sum_f moments[b,f,8]) / n_sequence  (sumQ :441-448, the
+ * per-ray sums fused into the trace kernel; rounded to float),  loss[b] = rms[b] + penalty_rate * penalty[b]  (:449).
+ * One launch instead of ~10 elementwise ones; same rounding points as that op sequence.
+ *   n_sequence: [B] doubles on the device (padded batches: rows of each lens' sequence), or NULL: n_sequence_all for all;
+ *   d_rms [B,F,TL_NMOM] double = d rms[b] / d moments[b], for tl_unsup_loss_bwd.
+ * tl_unsup_loss_bwd: g_moments [B,F,TL_NMOM] = d(sum_b g_loss[b] loss[b] + g_rms[b] rms[b] + g_penalty[b] penalty[b]) /
+ *   d moments; each upstream gradient nullable (not all three), element b at g[b * g_stride] (g_stride 0: one value for all).
+ */
+int tl_unsup_loss(int32_t device, int32_t B, int32_t F, double n_per_field, const double *moments, const double *n_sequence,
+                  double n_sequence_all, float penalty_rate, float *loss, float *rms, float *penalty, double *d_rms,
+                  void *stream);
+int tl_unsup_loss_bwd(int32_t device, int32_t B, int32_t F, const double *d_rms, const float *g_loss, const float *g_rms,
+                      const float *g_penalty, int32_t g_stride, const double *n_sequence, double n_sequence_all,
+                      float penalty_rate, double *g_moments, void *stream);
+
 /* d(loss)/dy, d(loss)/dx per ray from d(loss)/d(moments); outputs [F,P,W]-strided like y. */
 int tl_spot_seed(int32_t device, int32_t F, int32_t P, int32_t W,
                  const float *x, const float *y, const uint8_t *ok,

@@ -146,3 +146,46 @@ def test_host_chains_agree_through_ray_tracer_with_ray_aiming_and_hooks(ta):
     (o1, g1), (o2, g2) = _both(run)
     _same(o1, o2, "loss_dict")
     _same(g1, g2, "leaf gradients")
+
+
+@pytest.mark.parametrize("n_seq_kind", ["int", "tensor"])
+def test_fused_loss_dict_equals_the_op_sequence_bit_for_bit(ta, n_seq_kind):
+    """unsupervised_loss[_batch] under the C++ host chain is ONE launch (tl_unsup_loss) and one autograd node; under the
+    Python chain it is the op sequence rms + rate * (q / n_seq).to(float32).  Values of the three loss_dict entries and the
+    leaf gradients must agree bit for bit -- also when 'rms' and 'penalty' are used next to 'loss_unsup' downstream."""
+    from torchoptics_amd import ray_tracing as rt
+    g = load_golden("G11_batch3_16x16")
+
+    def run():
+        ins = [torch.from_numpy(g[n]).to(DEV) for n in IN]
+        mask = torch.from_numpy(g["in_mask"]).to(DEV)
+        lv = [ins[i].clone().requires_grad_(True) for i in (2, 4, 5, 6, 7)]
+        out = ta.trace_skew(ins[0], ins[1], lv[0], ins[3], lv[1], lv[2], lv[3], lv[4], mask, "sum", True)
+        n_seq = 8 if n_seq_kind == "int" else torch.tensor([8., 7., 5.], dtype=torch.float64, device=DEV)
+        ld = rt.unsupervised_loss_batch(out, n_seq, 0.2)
+        w = torch.tensor([1.0, -0.5, 2.0], device=DEV)
+        ((ld["loss_unsup"] * w).sum() + 0.3 * ld["rms"][1] - 1e-3 * ld["penalty"].sum()).backward()
+        return [ld[k].detach() for k in ("loss_unsup", "rms", "penalty")], [q.grad for q in lv]
+    (o1, g1), (o2, g2) = _both(run)
+    _same(o1, o2, "loss_dict")
+    _same(g1, g2, "gradients")
+    assert all(torch.isfinite(q).all() for q in g1)
+
+
+def test_fused_loss_dict_of_one_lens(ta):
+    """B = 1: unsupervised_loss (0-dim entries, as the reference's compute_loss_out) -- fused under the C++ chain."""
+    from torchoptics_amd import ray_tracing as rt
+    g = load_golden("G4_tessar_32x32")
+
+    def run():
+        ins = [torch.from_numpy(g[n]).to(DEV) for n in IN]
+        mask = torch.from_numpy(g["in_mask"]).to(DEV)
+        lv = [ins[i].clone().requires_grad_(True) for i in (2, 4, 5, 6, 7)]
+        out = ta.trace_skew(ins[0], ins[1], lv[0], ins[3], lv[1], lv[2], lv[3], lv[4], mask, "sum", True)
+        ld = rt.unsupervised_loss(out, ins[5].shape[-1], 0.2)
+        assert all(ld[k].dim() == 0 and ld[k].dtype == torch.float32 for k in ld)
+        ld["loss_unsup"].backward()
+        return [ld[k].detach() for k in ("loss_unsup", "rms", "penalty")], [q.grad for q in lv]
+    (o1, g1), (o2, g2) = _both(run)
+    _same(o1, o2, "loss_dict")
+    _same(g1, g2, "gradients")

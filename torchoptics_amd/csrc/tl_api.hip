@@ -231,6 +231,68 @@ __global__ __launch_bounds__(64) void spot_rms_kernel(const double *__restrict__
     if (threadIdx.x == 0) *rms = (float)(acc / (double)F);
 }
 
+// loss_dict of compute_loss_out (optics_simulator_lite.py:430-450) per lens, on the moments: rms as spot_rms_kernel,
+// penalty = (sum_f M8) / n_sequence rounded to fp32, loss_unsup = rms + rate * penalty in fp32 (the rounding points of the
+// op sequence  rms + penalty_rate * (q / n_seq).to(float32)  it replaces).  One block per lens.
+__global__ __launch_bounds__(64) void unsup_loss_kernel(const double *__restrict__ mom, int F, double n,
+                                                        const double *__restrict__ n_seq, double n_seq_all, float rate,
+                                                        float *__restrict__ loss, float *__restrict__ rms,
+                                                        float *__restrict__ pen, double *__restrict__ dmom)
+{
+#pragma clang fp contract(off)
+    const int b = blockIdx.x;
+    mom += (size_t)b * F * TL_NMOM;
+    dmom += (size_t)b * F * TL_NMOM;
+    double acc = 0.0, q = 0.0;
+    for (int f = threadIdx.x; f < F; f += 64) {
+        const double *M = mom + (size_t)f * TL_NMOM;
+        const double m = M[0] / n;
+        const double var = (M[2] - 2.0 * m * M[1] + m * m * M[3]) / n;
+        const double sd = sqrt(var);
+        acc += sd;
+        q += M[8];
+        const double k = var > 0.0 ? 1.0 / (2.0 * (double)F * n * sd) : 0.0;
+        double *D = dmom + (size_t)f * TL_NMOM;
+        for (int j = 0; j < TL_NMOM; ++j) D[j] = 0.0;
+        D[0] = k * (-2.0 * M[1] + 2.0 * m * M[3]) / n;
+        D[1] = -2.0 * m * k;
+        D[2] = k;
+        D[3] = m * m * k;
+    }
+    for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o, 64); q += __shfl_xor(q, o, 64); }
+    if (threadIdx.x == 0) {
+        const float r = (float)(acc / (double)F);
+        // (a tensor divided by a host scalar is a multiplication by its reciprocal in PyTorch's kernels: same here)
+        const float pn = (float)(n_seq ? q / n_seq[b] : q * (1.0 / n_seq_all));
+        const float prod = rate * pn;
+        rms[b] = r;
+        pen[b] = pn;
+        loss[b] = r + prod;
+    }
+}
+
+// d(sum_b g_loss[b] loss[b] + g_rms[b] rms[b] + g_pen[b] penalty[b]) / d moments, with the same rounding points as
+// autograd over the op sequence: the fp32 sums g_loss + g_rms and rate * g_loss + g_pen, then fp64
+__global__ __launch_bounds__(kBlock) void unsup_loss_bwd_kernel(const double *__restrict__ dmom, int F, int total,
+                                                                const float *__restrict__ g_loss, const float *__restrict__ g_rms,
+                                                                const float *__restrict__ g_pen, int g_stride,
+                                                                const double *__restrict__ n_seq, double n_seq_all, float rate,
+                                                                double *__restrict__ gmom)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / (F * TL_NMOM), j = i % TL_NMOM;
+    const int gb = b * g_stride;
+    float a = 0.0f, c = 0.0f;
+    if (g_loss) { a = g_loss[gb]; c = rate * g_loss[gb]; }
+    if (g_rms) a = g_loss ? a + g_rms[gb] : g_rms[gb];
+    if (g_pen) c = g_loss ? c + g_pen[gb] : g_pen[gb];
+    double v = dmom[i] * (double)a;
+    if (j == 8) v += n_seq ? (double)c / n_seq[b] : (double)c * (1.0 / n_seq_all);
+    gmom[i] = v;
+}
+
 // ---------------------------------------------------------------- spot kernels (strided tensors)
 __global__ __launch_bounds__(kBlock) void spot_moments_kernel(int P, int W, const float *__restrict__ x,
                                                               const float *__restrict__ y,
@@ -734,6 +796,39 @@ int tl_spot_rms(int32_t device, int32_t B, int32_t F, double n_per_field, const 
     hipLaunchKernelGGL(spot_rms_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, moments, F, n_per_field, rms, d_moments);
     const int herr = (int)hipGetLastError();
     if (herr) return hip_fail(herr, "spot_rms_kernel launch");
+    return TL_OK;
+}
+
+int tl_unsup_loss(int32_t device, int32_t B, int32_t F, double n_per_field, const double *moments, const double *n_sequence,
+                  double n_sequence_all, float penalty_rate, float *loss, float *rms, float *penalty, double *d_rms,
+                  void *stream)
+{
+    if (B < 1 || F < 1 || !(n_per_field > 0.0) || !moments || !loss || !rms || !penalty || !d_rms ||
+        (!n_sequence && !(n_sequence_all > 0.0)))
+        return fail(TL_EINVAL, "tl_unsup_loss: bad argument");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    hipLaunchKernelGGL(unsup_loss_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, moments, F, n_per_field, n_sequence,
+                       n_sequence_all, penalty_rate, loss, rms, penalty, d_rms);
+    const int herr = (int)hipGetLastError();
+    if (herr) return hip_fail(herr, "unsup_loss_kernel launch");
+    return TL_OK;
+}
+
+int tl_unsup_loss_bwd(int32_t device, int32_t B, int32_t F, const double *d_rms, const float *g_loss, const float *g_rms,
+                      const float *g_penalty, int32_t g_stride, const double *n_sequence, double n_sequence_all,
+                      float penalty_rate, double *g_moments, void *stream)
+{
+    if (B < 1 || F < 1 || !d_rms || !g_moments || (!g_loss && !g_rms && !g_penalty) || (g_stride != 0 && g_stride != 1) ||
+        (!n_sequence && !(n_sequence_all > 0.0)))
+        return fail(TL_EINVAL, "tl_unsup_loss_bwd: bad argument");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    const int total = B * F * TL_NMOM;
+    hipLaunchKernelGGL(unsup_loss_bwd_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, d_rms, F,
+                       total, g_loss, g_rms, g_penalty, g_stride, n_sequence, n_sequence_all, penalty_rate, g_moments);
+    const int herr = (int)hipGetLastError();
+    if (herr) return hip_fail(herr, "unsup_loss_bwd_kernel launch");
     return TL_OK;
 }
 

@@ -484,6 +484,76 @@ public:
 
 Tensor pupil_position(const Tensor &c, const Tensor &t, const Tensor &n, int64_t mode) { return PupilPositionFn::apply(c, t, n, mode); }
 
+// loss_dict of compute_loss_out per lens on the moments of an aggregate trace (tl_unsup_loss): (loss_unsup, rms, penalty),
+// each [n_lens] (0-dim for n_lens = 1, like the op sequence of ray_tracing.unsupervised_loss it replaces)
+class UnsupLossFn : public torch::autograd::Function<UnsupLossFn> {
+public:
+    static variable_list forward(AutogradContext *ctx, Tensor moments, double n_per_field, int64_t n_lens,
+                                 const c10::optional<Tensor> &n_seq, double n_seq_all, double rate)
+    {
+        require_device(moments, "moments");
+        const at::Device dev = moments.device();
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+        const hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
+        const Tensor m = moments.to(at::kDouble).contiguous();
+        Tensor ns;
+        if (n_seq && n_seq->defined()) {
+            ns = n_seq->to(dev, at::kDouble).reshape({-1}).contiguous();
+            TORCH_CHECK(ns.numel() == n_lens, "n_sequence must hold one entry per lens");
+        }
+        const auto fopt = m.options().dtype(at::kFloat);
+        const auto shape = n_lens == 1 ? std::vector<int64_t>{} : std::vector<int64_t>{n_lens};
+        Tensor loss = at::empty(shape, fopt), rms = at::empty(shape, fopt), pen = at::empty(shape, fopt);
+        Tensor dm = at::empty_like(m);
+        check(tl_unsup_loss(dev.index(), (int32_t)n_lens, (int32_t)(m.size(0) / n_lens), n_per_field, (const double *)m.data_ptr(),
+                            (const double *)ptr(ns), n_seq_all, (float)rate, (float *)loss.data_ptr(), (float *)rms.data_ptr(),
+                            (float *)pen.data_ptr(), (double *)dm.data_ptr(), (void *)st),
+              "tl_unsup_loss");
+        ctx->save_for_backward({dm, ns});
+        ctx->saved_data["n_lens"] = n_lens;
+        ctx->saved_data["n_seq_all"] = n_seq_all;
+        ctx->saved_data["rate"] = rate;
+        return {loss, rms, pen};
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list g)
+    {
+        variable_list out(6);
+        if (!g[0].defined() && !g[1].defined() && !g[2].defined()) return out;
+        const auto sv = ctx->get_saved_variables();
+        const Tensor dm = sv[0], ns = sv[1];
+        const int64_t n_lens = ctx->saved_data["n_lens"].toInt();
+        const at::Device dev = dm.device();
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+        const hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
+        // upstream gradients: [n_lens] dense, or one value for every lens (an expanded scalar: stride 0)
+        Tensor gg[3];
+        bool uniform = n_lens > 1;
+        for (int i = 0; i < 3; ++i) {
+            if (!g[i].defined()) continue;
+            gg[i] = f32(g[i]).reshape({-1});
+            if (n_lens > 1 && gg[i].stride(0) != 0) uniform = false;
+        }
+        if (!uniform)
+            for (auto &t : gg) if (t.defined()) t = t.contiguous();
+        const int64_t stride = uniform ? 0 : 1;
+        Tensor gm = at::empty_like(dm);
+        check(tl_unsup_loss_bwd(dev.index(), (int32_t)n_lens, (int32_t)(dm.size(0) / n_lens), (const double *)dm.data_ptr(),
+                                (const float *)ptr(gg[0]), (const float *)ptr(gg[1]), (const float *)ptr(gg[2]), (int32_t)stride,
+                                (const double *)ptr(ns), ctx->saved_data["n_seq_all"].toDouble(),
+                                (float)ctx->saved_data["rate"].toDouble(), (double *)gm.data_ptr(), (void *)st),
+              "tl_unsup_loss_bwd");
+        out[0] = gm;
+        return out;
+    }
+};
+
+std::vector<Tensor> unsup_loss(const Tensor &moments, double n_per_field, int64_t n_lens, const c10::optional<Tensor> &n_seq,
+                               double n_seq_all, double rate)
+{
+    return UnsupLossFn::apply(moments, n_per_field, n_lens, n_seq, n_seq_all, rate);
+}
+
 std::vector<Tensor> trace(const Tensor &x, const Tensor &y, const Tensor &z, const Tensor &cx, const Tensor &cy, const Tensor &c,
                           const Tensor &t, const Tensor &mu, const Tensor &mask, const c10::optional<Tensor> &kappa,
                           const c10::optional<Tensor> &poly, const c10::optional<Tensor> &kind,
@@ -505,6 +575,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("trace", &trace);
     m.def("spot_rms", &spot_rms);
     m.def("pupil_position", &pupil_position);
+    m.def("unsup_loss", &unsup_loss);
     m.def("last_use_inv", [] { return g_last_use_inv; });
     m.def("enable_timing", &enable_timing);
     m.def("timing_ms", &timing_ms);

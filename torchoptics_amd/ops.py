@@ -583,6 +583,17 @@ def pupil_position(c, t, n, mode=None):
     return PupilPositionFunction.apply(c, t, n, mode)
 
 
+def unsup_loss(moments, n_per_field, n_lens, n_sequence, penalty_rate):
+    """(loss_unsup, rms, penalty) per lens from the moments of an aggregate trace in one launch (tl_unsup_loss), or None
+    when the C++ host chain is not active (the callers then compose the same values from tensor ops)."""
+    ext = _ext()
+    if ext is None or not moments.is_cuda or not hasattr(ext, "unsup_loss"):
+        return None
+    if isinstance(n_sequence, (int, float)):
+        return ext.unsup_loss(moments, float(n_per_field), int(n_lens), None, float(n_sequence), float(penalty_rate))
+    return ext.unsup_loss(moments, float(n_per_field), int(n_lens), torch.as_tensor(n_sequence), 0.0, float(penalty_rate))
+
+
 def spot_rms(moments, n_per_field, n_lens=1):
     """compute_rms2d on the moments (SpotRmsFunction), through the C++ host extension when it is there."""
     ext = _ext()

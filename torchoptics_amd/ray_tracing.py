@@ -416,9 +416,28 @@ def unsupervised_loss(rt_outputs, n_sequence: int, penalty_rate: float):
     {'loss_unsup': rms + penalty_rate * sumQ, 'rms': rms, 'penalty': sumQ} from the 7-tuple that
     trace_rays(..., aggregate=True) returns."""
     x, y, *_, ray_ok, _ray_backward, stacks = rt_outputs
+    fused = _fused_unsup_loss(y, ray_ok, stacks, n_sequence, penalty_rate, 1)
+    if fused is not None:
+        return fused
     rms = compute_rms2d(x, y, ray_ok)
     pen = penalty_sum(stacks, n_sequence)
     return {'loss_unsup': rms + penalty_rate * pen, 'rms': rms, 'penalty': pen}
+
+
+def _fused_unsup_loss(y, ray_ok, stacks, n_sequence, penalty_rate, n_lens):
+    """The loss_dict in ONE launch (tl_unsup_loss, C++ host chain) when everything it needs is the fused moments of an
+    aggregate trace of fp32 tensors on the GPU; None otherwise (the callers compose it from tensor ops: same values)."""
+    tag = getattr(y, "_tl_spot", None)
+    if (not isinstance(stacks, PenaltyStacks) or tag is None or tag[1] is not ray_ok or tag[2] != y._version
+            or stacks._moments is not tag[0] or y.dtype != torch.float32 or not isinstance(penalty_rate, (int, float))):
+        return None
+    moments = tag[0]
+    if n_lens == 1 and y.shape[0] > 1:
+        return None                     # compute_rms2d reads sample 0 of a batch, the penalty sums all of it: not this kernel
+    out = ops.unsup_loss(moments, tag[3], n_lens, n_sequence, penalty_rate)
+    if out is None:
+        return None
+    return {'loss_unsup': out[0], 'rms': out[1], 'penalty': out[2]}
 
 
 def unsupervised_loss_batch(rt_outputs, n_sequence, penalty_rate: float):
@@ -427,6 +446,9 @@ def unsupervised_loss_batch(rt_outputs, n_sequence, penalty_rate: float):
     batched trace.  `n_sequence`: rows of the sequence string per lens (an int, or a [B] tensor for padded batches:
     compute_loss_out divides by len(self._sequence[0]))."""
     x, y, *_, ray_ok, _ray_backward, stacks = rt_outputs
+    fused = _fused_unsup_loss(y, ray_ok, stacks, n_sequence, penalty_rate, y.shape[0])
+    if fused is not None:
+        return fused
     rms = compute_rms2d_batch(x, y, ray_ok)
     if isinstance(stacks, PenaltyStacks):
         q = stacks.q_per_lens
