@@ -72,9 +72,15 @@ Plan plan_fwd(const tl_problem *p)
 
 Plan plan_bwd(const tl_problem *p)
 {
+    // 16 rays per lane once there is work for >= 4096 such blocks (8 per lane and 2048 blocks in the forward): the
+    // walk-back's per-block prologue (LDS rows, accumulator slots) and partial row are paid half as often: -1...2 % at
+    // 16.8 M rays on every workload; at 8.4 M rays (2048 blocks of 16: a 1.3-round tail at 6 waves per SIMD) it stays at 8.
+    // A/B tools/sessions/r3_s32.txt, r3_s33.txt
     static const int cap = env_int("TL_BWD_BLOCKS", 8192), rmax = env_int("TL_BWD_RMAX", 64);
     static const int few = env_int("TL_PLAN_FEW", 2048), rwant = env_int("TL_PLAN_R", 8);
-    return make_plan(p->P, rows_bfw(p), cap, rmax, few, rwant);
+    static const int rbig = env_int("TL_BWD_PLAN_R", 16), big = env_int("TL_BWD_PLAN_BIG", 4096);
+    const int64_t chunks = ((int64_t)p->P + kBlock - 1) / kBlock;
+    return make_plan(p->P, rows_bfw(p), cap, rmax, few, chunks * rows_bfw(p) >= (int64_t)rbig * big ? rbig : rwant);
 }
 
 int check_problem(const tl_problem *p)
