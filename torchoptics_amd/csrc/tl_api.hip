@@ -126,7 +126,17 @@ __device__ __forceinline__ double sum_rows(const double *part, int64_t nrows, in
     double acc = 0.0;
     for (int f = f0; f < f0 + nf; ++f) {
         const double *run = colp + ((int64_t)f * W + w0) * nbx;
-        for (int i = threadIdx.x; i < count; i += kBlock) acc += run[i];
+        // eight independent loads and four partial sums per trip: with one load per trip the kernel spent its ~12 us on 32
+        // dependent load latencies per thread (8192 partial rows at 16.8 M rays).  Still one fixed summation order.
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int i = threadIdx.x;
+        for (; i + 7 * kBlock < count; i += 8 * kBlock) {
+            const double v0 = run[i], v1 = run[i + kBlock], v2 = run[i + 2 * kBlock], v3 = run[i + 3 * kBlock];
+            const double v4 = run[i + 4 * kBlock], v5 = run[i + 5 * kBlock], v6 = run[i + 6 * kBlock], v7 = run[i + 7 * kBlock];
+            a0 += v0 + v4; a1 += v1 + v5; a2 += v2 + v6; a3 += v3 + v7;
+        }
+        for (; i < count; i += kBlock) a0 += run[i];
+        acc += (a0 + a1) + (a2 + a3);
     }
     return block_sum_256(acc, sm);
 }
@@ -161,19 +171,14 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
     // and the walk-back's poison word (== this call's token) say which of the two launches did the work (same rule as
     // fallback_needed in tl_kernels.inc).  add_alt (penalty term): when the walk-back did its work, the checkpoint
     // launch behind it took the rays that died on the way -- the result is the SUM of the two arrays.
-    const double *part2 = nullptr;
-    int NS2 = 0, nbx2 = 0;
+    // The count and the word are read FIRST and looked at LAST: the sum over the walk-back's array -- nearly always the
+    // one that counts -- is formed while those loads are in flight (two dependent round trips off this tiny kernel).
+    double n_ill = 0.0;
+    unsigned pz = 0u;
     if (alt_part) {
-        double n = 0.0;
         if (fmom)
-            for (int f = 0; f < F * (int)gridDim.y; ++f) n += fmom[(size_t)f * TL_NMOM + 9];
-        // add_alt bit 1: the forward left per-ray conditioning flags (tl_problem.cond_flags), so ill-conditioned rays
-        // (n > 0) were split between the two launches as well, instead of sending the whole launch to the checkpoint kernel
-        if ((n > 0.0 && !(add_alt & 2)) || (poison && *poison == token)) {
-            part = alt_part; NS = alt_NS; ncol = tl_bwd_row(alt_NS, g_kappa != nullptr); nbx = alt_nbx;
-        } else if ((add_alt & 1) || n > 0.0) {
-            part2 = alt_part; NS2 = alt_NS; nbx2 = alt_nbx;
-        }
+            for (int f = 0; f < F * (int)gridDim.y; ++f) n_ill += fmom[(size_t)f * TL_NMOM + 9];
+        if (poison) pz = *poison;
     }
     // one block per output scalar: g_c[S] | g_t[S] | g_mu[W,S] | g_z | g_cx[F] | g_cy[F] [| g_kappa[S] | g_poly[S,4]] [| g_n[W,S+1]]
     // of lens blockIdx.y, whose partial rows are those of the fields [lens F, (lens + 1) F)
@@ -202,9 +207,16 @@ __global__ __launch_bounds__(kBlock) void reduce_bwd_kernel(const double *__rest
     }
     (void)ncol;
     double s = sum_rows(part, (int64_t)gridDim.y * F * W * nbx, ca * NS + c0, W, nbx, lens * F + f0, nf, w0, nw, sm);
-    if (part2) {
-        __syncthreads();                          // sm is reused
-        s += sum_rows(part2, (int64_t)gridDim.y * F * W * nbx2, ca * NS2 + c0, W, nbx2, lens * F + f0, nf, w0, nw, sm);
+    if (alt_part) {
+        // add_alt bit 1: the forward left per-ray conditioning flags (tl_problem.cond_flags), so ill-conditioned rays
+        // (n_ill > 0) were split between the two launches as well, instead of sending the whole launch to the checkpoint kernel
+        const bool alt_only = (n_ill > 0.0 && !(add_alt & 2)) || (poison && pz == token);
+        if (alt_only || (add_alt & 1) || n_ill > 0.0) {
+            __syncthreads();                          // sm is reused
+            const double s2 = sum_rows(alt_part, (int64_t)gridDim.y * F * W * alt_nbx, ca * alt_NS + c0, W, alt_nbx,
+                                       lens * F + f0, nf, w0, nw, sm);
+            s = alt_only ? s2 : s + s2;
+        }
     }
     if (threadIdx.x == 0) *out = (float)s;        // summed in fp64, rounded once
 }
