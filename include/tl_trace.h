@@ -277,6 +277,16 @@ int tl_ray_aim(int32_t device, int32_t B, int32_t F, int32_t W, int32_t K, const
                float *x_scale, float *y_scale, float *y_offset, void *stream);
 
 /*
+ * The aimed fan, [B,F,W,P] floats (consecutive pupil points contiguous), from one shared relative pupil grid xp, yp [P] and
+ * tl_ray_aim's map:  x = clamp(xp x_scale, -2, 2) epd / 2,  y = clamp(yp y_scale + y_offset, -2, 2) epd / 2
+ * (RayTracer.trace_rays, ray_tracing_lite.py:104-113: remap, torch.clamp(-2, 2), scale_to_epd) -- one launch for seven,
+ * same rounding points.  x_scale, y_scale, y_offset [B,F,W]; epd [B].
+ */
+int tl_aim_fan(int32_t device, int32_t B, int32_t F, int32_t W, int32_t P, const float *xp, const float *yp,
+               const float *x_scale, const float *y_scale, const float *y_offset, const float *epd, float *x_out, float *y_out,
+               void *stream);
+
+/*
  * Double precision -- RayTracer(double_precision=True) (ray_tracing_lite.py:82-84; the reference crashes there: Specs and
  * Lens have no .double()).  The same trace, forward and checkpoint backward, entirely in fp64: generic,
  * untuned kernels (one ray per lane, rolled loops) for reference-quality numbers on the GPU, not for speed.

@@ -99,3 +99,30 @@ def test_minibatch_of_lenses_through_the_aiming_kernel(ta):
     (l1, g1), (l2, g2) = res
     assert ((l1 - l2).abs() / l2.abs()).max().item() < 2e-5
     assert ((g1 - g2).norm() / g2.norm()).item() < 1e-3          # the penalty gradient's own fp32 noise level
+
+
+@pytest.mark.parametrize("name", ["cooke", "tessar"])
+def test_one_launch_fan_equals_remap_clamp_scale_bit_for_bit(ta, name):
+    """tl_aim_fan (the aimed, clamped, pupil-scaled fan in one launch, laid out [B,F,W,P]) against the three tensor-op steps of
+    RayTracer.assemble it replaces -- remap, torch.clamp(-2, 2), scale_to_epd -- on a fan wide enough for the clamp to act."""
+    import yaml_free_lenses as L
+    from torchoptics_amd import ray_tracing as rt
+    lens, specs, _ = L.build(name, DEV, grad=False, epd=12.0, hfov_deg=30.0)
+    tr = ta.RayTracer(mode="circular", n_rays=(16, 16), rel_fields=(0., 0.5, 0.707, 1.), wavelengths=("C", "d", "F"),
+                      n_ray_aiming_iter=1, default_device=DEV)
+    aim = tr.ray_aiming(specs, lens.detach(), True)
+    assert callable(getattr(aim, "fan", None))
+    xp, yp = rt.circle(None, 16, 16, DEV)
+    xp, yp = 2.5 * xp, 2.5 * yp                                # beyond the clamp for part of the grid
+    fx, fy = aim.fan(xp, yp, specs.epd)
+    ox, oy = (rt.scale_to_epd(torch.clamp(v, -2, 2), specs.epd) for v in aim(xp, yp))
+    assert fx.shape == ox.shape and fx.stride(2) == 1           # consecutive pupil points are contiguous
+    assert torch.equal(fx, ox) and torch.equal(fy, oy)
+    assert (torch.clamp(aim(xp, yp)[0], -2, 2) != aim(xp, yp)[0]).any()
+    # not a shared [1,1,P,1] fan: the caller composes it from tensor ops
+    assert aim.fan(xp.expand(1, 4, -1, 1), yp.expand(1, 4, -1, 1), specs.epd) is None
+    # and the assembled fan of trace_rays is that one-launch fan
+    a = tr.assemble(specs, lens)
+    xq, yq = rt.circle(None, 16, 16, DEV)
+    gx, gy = aim.fan(xq, yq, specs.epd)
+    assert torch.equal(a["x"], gx) and torch.equal(a["y"], gy) and a["x"].stride(2) == 1

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "tl_unsup_loss": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, _VP, _VP, C.c_double, C.c_float, _VP, _VP, _VP, _VP, _VP]),
     "tl_unsup_loss_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, C.c_int32, _VP, C.c_double, C.c_float,
                                     _VP, _VP]),
+    "tl_aim_fan": (C.c_int, [C.c_int32] * 5 + [_VP] * 9),
     "tl_spot_seed": (C.c_int, [C.c_int32] * 4 + [_VP] * 3 + [C.c_int64] * 3 + [_VP] * 4),
     "tl_pupil_position": (C.c_int, [C.c_int32] * 3 + [_VP] * 8 + [C.c_int32, _VP]),
     "tl_workspace_bytes_f64": (C.c_size_t, [C.POINTER(tl_problem)]),

@@ -880,6 +880,45 @@ int tl_pupil_position(int32_t device, int32_t B, int32_t K, const float *c, cons
     return TL_OK;
 }
 
+// The aimed fan in one launch: x = clamp(xp x_scale, -2, 2) (epd / 2), y = clamp(yp y_scale + y_offset, -2, 2) (epd / 2) --
+// the op sequence of RayTracer.assemble after ray_aiming (remap, clamp, scale_to_epd: 7 elementwise launches), with its
+// rounding points (no contraction).  Output laid out [B,F,W,P]: the trace kernels read consecutive pupil points.
+__global__ __launch_bounds__(kBlock) void aim_fan_kernel(int P, int F, int W, const float *__restrict__ xp,
+                                                         const float *__restrict__ yp, const float *__restrict__ x_scale,
+                                                         const float *__restrict__ y_scale, const float *__restrict__ y_offset,
+                                                         const float *__restrict__ epd, float *__restrict__ x_out,
+                                                         float *__restrict__ y_out)
+{
+#pragma clang fp contract(off)
+    const int bfw = blockIdx.y, b = bfw / (F * W);
+    const int ip = blockIdx.x * kBlock + threadIdx.x;
+    if (ip >= P) return;
+    const float xs = x_scale[bfw], ys = y_scale[bfw], yo = y_offset[bfw], half = epd[b] / 2.0f;
+    float x = xp[ip] * xs;
+    float y = yp[ip] * ys;
+    y = y + yo;
+    x = fminf(fmaxf(x, -2.0f), 2.0f);
+    y = fminf(fmaxf(y, -2.0f), 2.0f);
+    x_out[(size_t)bfw * P + ip] = x * half;
+    y_out[(size_t)bfw * P + ip] = y * half;
+}
+
+int tl_aim_fan(int32_t device, int32_t B, int32_t F, int32_t W, int32_t P, const float *xp, const float *yp,
+               const float *x_scale, const float *y_scale, const float *y_offset, const float *epd, float *x_out, float *y_out,
+               void *stream)
+{
+    if (B < 1 || F < 1 || W < 1 || P < 1 || !xp || !yp || !x_scale || !y_scale || !y_offset || !epd || !x_out || !y_out)
+        return fail(TL_EINVAL, "tl_aim_fan: bad argument");
+    if ((int64_t)B * F * W > 65535) return fail(TL_EINVAL, "B*F*W exceeds 65535");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    hipLaunchKernelGGL(aim_fan_kernel, dim3((P + kBlock - 1) / kBlock, B * F * W), dim3(kBlock), 0, (hipStream_t)stream, P, F, W, xp,
+                       yp, x_scale, y_scale, y_offset, epd, x_out, y_out);
+    const int herr = (int)hipGetLastError();
+    if (herr) return hip_fail(herr, "aim_fan_kernel launch");
+    return TL_OK;
+}
+
 int tl_ray_aim(int32_t device, int32_t B, int32_t F, int32_t W, int32_t K, const float *c, const float *t, const float *n,
                const float *n_d, const uint8_t *mask, const float *kappa, const float *poly, const uint8_t *surf_kind,
                const float *z, const float *hfov, const float *fields, const float *epd, int32_t allow_backward,

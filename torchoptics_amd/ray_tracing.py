@@ -604,12 +604,16 @@ class RayTracer:
         front = lens.up_to_stop()
         z1 = compute_pupil_position(lens, self.arith, front=front)
         z = z1.reshape(-1, 1, 1, 1)
+        xy_abs = None
         xp_rel, yp_rel = self.pupil_span(z) if xy is None else xy
         if use_vig and self.vig_fn is not None and self.mode != 'chief':
             yp_rel, xp_rel = self._vignette(specs, yp_rel.to(dev), xp_rel.to(dev))
         if self.n_ray_aiming_iter > 0 and not up_to_stop:
             aim = self.ray_aiming(specs, lens, use_vig, front=front, z=z1.detach())
-            xp_rel, yp_rel = (torch.clamp(v, -2, 2).to(dev).detach() for v in aim(xp_rel, yp_rel))
+            fan = getattr(aim, "fan", None)        # the aiming kernel's one-launch form of the three steps below
+            xy_abs = fan(xp_rel, yp_rel, specs.epd) if fan is not None else None
+            if xy_abs is None:
+                xp_rel, yp_rel = (torch.clamp(v, -2, 2).to(dev).detach() for v in aim(xp_rel, yp_rel))
         from .lens_modeling import const_tensor
         fields = const_tensor(list(self.rel_fields), torch.float32, dev)
         # strict: the correctly rounded fp32 sine (evaluated in fp64, rounded once) -- the reference's value on every CPU
@@ -619,8 +623,9 @@ class RayTracer:
             return torch.sin(ang.double()).to(ang.dtype) if (strict and ang.is_cuda and ang.dtype == torch.float32) else torch.sin(ang)
         cy = _memoised("cy", (strict,), (specs.hfov, fields), (specs.hfov,), sines)
         cx = const_tensor([0.0], torch.float32, dev, (1, 1, 1, 1))
+        x_abs, y_abs = xy_abs if xy_abs is not None else (scale_to_epd(xp_rel.to(dev), specs.epd), scale_to_epd(yp_rel.to(dev), specs.epd))
         out = dict(
-            x=scale_to_epd(xp_rel.to(dev), specs.epd), y=scale_to_epd(yp_rel.to(dev), specs.epd), z=z, cx=cx, cy=cy,
+            x=x_abs, y=y_abs, z=z, cx=cx, cy=cy,
             c=lens.c.reshape(lens.c.shape[0], 1, 1, 1, -1), t=lens.t.reshape(lens.t.shape[0], 1, 1, 1, -1),
             mu=_memoised("mu", (), (n,), (n,), lambda: n[..., :-1] / n[..., 1:]),
             mask=lens.structure.mask_torch.reshape(lens.c.shape[0], 1, 1, 1, -1))
@@ -687,6 +692,23 @@ class RayTracer:
 
         def remap(xp_rel, yp_rel):
             return xp_rel * x_scale, yp_rel * y_scale + y_offset
+
+        def fan(xp_rel, yp_rel, epd_full):
+            """clamp(remap(.), -2, 2) scaled to the pupil, [B,F,P,W] (memory [B,F,W,P]), in ONE launch (tl_aim_fan) -- or
+            None when the pupil grid is not one shared fp32 [1,1,P,1] fan (the caller then composes it from tensor ops)."""
+            P = xp_rel.shape[2] if xp_rel.dim() == 4 else 0
+            if (P == 0 or tuple(xp_rel.shape) != (1, 1, P, 1) or tuple(yp_rel.shape) != (1, 1, P, 1) or B * F * W > 65535
+                    or not (xp_rel.is_cuda and yp_rel.is_cuda and xp_rel.dtype == yp_rel.dtype == torch.float32)
+                    or epd_full.requires_grad or xp_rel.requires_grad or yp_rel.requires_grad):
+                return None
+            xp, yp, e = _dense(xp_rel.detach()), _dense(yp_rel.detach()), _dense(epd_full.detach().float())
+            xy = torch.empty((2, B, F, W, P), dtype=torch.float32, device=dev)
+            with ops._on_device(dev):
+                rc2 = _lib.lib().tl_aim_fan(dev.index, B, F, W, P, _lib.ptr(xp), _lib.ptr(yp), _lib.ptr(x_scale), _lib.ptr(y_scale),
+                                            _lib.ptr(y_offset), _lib.ptr(e), _lib.ptr(xy[0]), _lib.ptr(xy[1]), ops._stream_ptr(dev))
+            _lib.check(rc2, "tl_aim_fan")
+            return xy[0].permute(0, 1, 3, 2), xy[1].permute(0, 1, 3, 2)
+        remap.fan = fan
         return remap
 
     # -- ray aiming (ray_tracing_lite.py:129-208) ---------------------------------------------
