@@ -175,8 +175,10 @@ int tl_trace_bwd(const tl_problem *p,
  * tl_trace_fwd), where it would reach 1e-4.  The call therefore always enqueues the checkpoint kernel of
  * tl_trace_bwd behind the walk-back kernel; both decide ON THE DEVICE which of them does the work (no host
  * synchronisation; the idle launch retires in microseconds).  The checkpoint kernel takes over when
- *   - `moments_fwd` (the forward's moments, nullable) counts an ill-conditioned live ray, or
- *   - the walk-back met a non-finite adjoint (it then flags a word at the end of the workspace).
+ *   - `moments_fwd` (the forward's moments, nullable) counts an ill-conditioned live ray -- for exactly those rays when
+ *     the forward left their flags in p->cond_flags (read in place of ok_fwd, which may then be NULL; the ok bytes given
+ *     otherwise must be 0 / 1 as tl_trace_fwd writes them), for the whole launch when it did not -- or
+ *   - the walk-back met a non-finite adjoint (it then flags a word at the end of the workspace): the whole launch.
  * Pass `moments_fwd` whenever it is available: without it an ill-conditioned fan is walked back anyway.
  * allow_backward = 1 only, no OPD gradient (TL_EINVAL otherwise: use tl_trace_bwd).  Aspheric rows are walked
  * back too (g_kappa, g_poly as in tl_trace_bwd, required iff p->surf_kind).
