@@ -629,7 +629,9 @@ size_t tl_workspace_bytes(const tl_problem *p)
     const size_t a = fw * pf.nbx * TL_NMOM * sizeof(double);
     const size_t b = fw * pb.nbx * (size_t)tl_bwd_row(ns < 0 ? TL_MAX_SURFACES : ns, p->surf_kind != nullptr) * sizeof(double);
     const size_t c = fw * pb.nbx * (size_t)((p->surf_kind ? 8 : 3) * p->S + 3) * sizeof(double);   // walk-back kernel next to its fallback
-    return (a > b + c ? a : b + c) + 256;
+    // + the penalty walk-back's scan map, right below the 256-byte slack at the end (the poison word lives in that slack)
+    const size_t scan = tl_scanmap_bytes(rows_bfw(p), ((int64_t)p->P + kBlock - 1) / kBlock);
+    return (a > b + c ? a : b + c) + scan + 256;
 }
 
 int tl_trace_fwd(const tl_problem *p, float *x, float *y, float *cx, float *cy, uint8_t *ok, uint8_t *back,
@@ -756,7 +758,8 @@ int tl_trace_bwd_from_outputs(const tl_problem *p, const float *gx, const float 
     const int ncol = (asph ? 8 : 3) * p->S + 3, ns = tl_bwd_bucket(p->S), ncol_ck = tl_bwd_row(ns, asph);
     const size_t rows = (size_t)rows_bfw(p) * pl.nbx, rows_ck = (size_t)rows_bfw(p) * pk.nbx;
     const size_t need_inv = rows * ncol * sizeof(double), need_ck = rows_ck * ncol_ck * sizeof(double);
-    if (!workspace || workspace_bytes < tl_workspace_bytes(p) || tl_workspace_bytes(p) < need_inv + need_ck + 256)
+    const size_t need_scan = tl_scanmap_bytes(rows_bfw(p), ((int64_t)p->P + kBlock - 1) / kBlock);
+    if (!workspace || workspace_bytes < tl_workspace_bytes(p) || tl_workspace_bytes(p) < need_inv + need_ck + need_scan + 256)
         return fail(TL_EWORKSPACE, "workspace too small for tl_trace_bwd_from_outputs");
     double *part = (double *)workspace, *part_ck = part + rows * ncol;
     unsigned *poison = poison_word(p, workspace);      // the walk-back writes `token` here on a non-finite adjoint

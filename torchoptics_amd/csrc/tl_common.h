@@ -22,6 +22,13 @@ __host__ __device__ static inline int tl_bwd_row(int ns, bool asph) { return (as
 // the smallest pupil it takes (no skip there for waves past the end of a small pupil).
 #define TL_INVU_MIN 3
 #define TL_INVU_MAX 20
+// bytes of the penalty walk-back's scan map (tl_kernels.inc: tl_scanmap): one per (row of the grid, 256-ray chunk, wave of
+// the 256-thread block), rounded up to 256
+__host__ __device__ static inline size_t tl_scanmap_bytes(int rows, int64_t nchunks)
+{
+    return (((size_t)rows * (size_t)nchunks * 4u) + 255u) & ~(size_t)255u;
+}
+
 static inline bool tl_walk_unrolled(int S, int P) { return S >= TL_INVU_MIN && S <= TL_INVU_MAX && P >= 256; }
 
 // per-mode launchers (defined in tl_strict.hip / tl_fast.hip); return hipError_t as int
