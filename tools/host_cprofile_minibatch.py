@@ -30,6 +30,22 @@ def step():
     ld["loss_unsup"].sum().backward()
 
 
+if "--loop" in sys.argv:
+    # the reference's caller's loop (optical_loss.py:96-110): one lens per call, B = 1, full stacks
+    n_l = 32
+    singles = []
+    for b_ in range(n_l):
+        lv = {k: leaves[k].detach().reshape(256, -1)[b_].clone() for k in ("c", "t", "nd", "v")}
+        lv["c"].requires_grad_(True), lv["t"].requires_grad_(True)
+        singles.append((st[b_], specs[b_], lv))
+
+    def step():          # noqa: F811
+        for st1, sp1, lv in singles[:8]:
+            lv["c"].grad = lv["t"].grad = None
+            lens = ta.Lens(st1, lv["c"], lv["t"], lv["nd"], lv["v"])
+            out = tracer.trace_rays(sp1, lens, aggregate=True)
+            rt.unsupervised_loss(out, n_seq, 0.2)["loss_unsup"].backward()
+
 for _ in range(30):
     step()
 torch.cuda.synchronize()

@@ -187,6 +187,7 @@ class Specs:
 # shape and dtype, so an in-place update of the source invalidates the entry (writes through `.data` do not
 # bump the version counter: they are the one way to defeat it, as they are for autograd itself).
 _memo = {}
+_MEMO_CAP = 8192
 
 
 def _memoised(tag, extra, key_tensors, grad_tensors, fn):
@@ -200,8 +201,12 @@ def _memoised(tag, extra, key_tensors, grad_tensors, fn):
                                 t.device) for t in key_tensors)
     hit = _memo.get(key)
     if hit is None or hit[0]._version != hit[1]:         # never computed, or somebody wrote into the cached result
-        if len(_memo) > 64:
-            _memo.clear()
+        if len(_memo) > _MEMO_CAP:
+            # drop the older half (dicts keep insertion order).  The cap is sized for a caller that loops over a minibatch of
+            # lenses one at a time (optical_loss.py:96-110): every lens brings ~10 entries of a few hundred bytes, and a cap
+            # below lenses x 10 means every call recomputes everything (64 did that to a 32-lens loop)
+            for k in list(_memo)[: len(_memo) // 2]:
+                del _memo[k]
         out = fn()
         # the entry keeps its key tensors alive: while it exists their storage cannot be freed and handed to
         # another tensor, so an equal (address, version, shape) key always means the same data
