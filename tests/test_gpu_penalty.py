@@ -192,3 +192,48 @@ def test_penalty_walk_back_takes_the_live_rays_and_the_checkpoint_pass_the_dead_
         #  ~2000 and fp32 autograd itself is 1e-4 from fp64, see the module docstring)
         lim = tol if n in ("c", "t", "mu") else 2e-3
         assert e_ck <= lim + 2 * noise and e64 <= lim + 2 * noise, f"{mode} d/d{n}: {e_ck:.2e} / {e64:.2e}"
+
+
+@pytest.mark.parametrize("log2p", [25, 20])
+def test_selective_pass_finds_sparse_dead_rays_in_a_large_fan(ta, log2p):
+    """The checkpoint pass behind the penalty walk-back reads the walk-back's scan map 64 chunks per look.  A fan of
+    2^25 + 37 pupil points puts 128 chunks on every block of that launch (two looks per wave, a ragged last chunk); 2^20 + 37
+    is the small-plan case.  Rays scattered over the fan (and the whole last, partial chunk) start outside the
+    aperture and die (0.1 % of the fan, scattered: most chunks hold none): the result must equal the checkpoint algorithm
+    on every ray up to the walk-back's rounding on the live ones; dropping the dead rays would show at ~1e-3."""
+    from torchoptics_amd import ops, ray_tracing as rt
+    g = load_golden("G4_tessar_32x32")
+    ins = [torch.from_numpy(g[n]).to(DEV) for n in IN]
+    mask = torch.from_numpy(g["in_mask"]).to(DEV)
+    S = ins[5].shape[-1]
+    P = (1 << log2p) + 37
+    gen = torch.Generator(DEV).manual_seed(3)
+    r = torch.sqrt(torch.rand(P, device=DEV, generator=gen)) * float(g["in_x"].max())
+    th = torch.rand(P, device=DEV, generator=gen) * 6.2831853
+    x, y = (r * torch.cos(th)), (r * torch.sin(th))
+    dead = torch.randint(0, P, (P // 1000,), device=DEV, generator=gen)       # 0.1 % of the fan: visible at the 2e-5 gate below
+    dead = torch.cat([dead, torch.arange(P - 37, P, device=DEV)])
+    x[dead] *= 40.0
+    y[dead] *= 40.0
+    x, y = x.reshape(1, 1, P, 1), y.reshape(1, 1, P, 1)
+    cy = ins[4][:, :1]                                           # one field, the fixture's three wavelengths
+    F, W = 1, ins[7].shape[3]
+    got = {}
+    for algo in ("inverse", "checkpoint"):
+        ops.set_backward_algorithm(algo)
+        try:
+            lv = [ins[i].clone().requires_grad_(True) for i in (5, 6, 7)]
+            o = ta.trace_skew(x.expand(1, F, P, W), y.expand(1, F, P, W), ins[2], ins[3], cy, lv[0], lv[1], lv[2], mask, "sum", True)
+            assert _used_walk_back(o[0]) is (algo == "inverse")
+            n_dead = int((~o[4]).sum().item())
+            (ta.compute_rms2d(o[0], o[1], o[4]) + 0.2 * rt.penalty_sum(o[6], S)).backward()
+            got[algo] = [q.grad.clone() for q in lv]
+            del o
+        finally:
+            ops.set_backward_algorithm("inverse")
+    assert P // 1000 <= n_dead <= 3 * (P // 1000 + 37) + 64
+    for n, a, b in zip(("c", "t", "mu"), got["inverse"], got["checkpoint"]):
+        e = rel_l2(a.cpu().numpy(), b.cpu().numpy())
+        print(f"2^{log2p} + 37 points, {n_dead} dead rays: d/d{n} walk-back + selective pass vs checkpoint {e:.2e}")
+        assert e <= 2e-5, n
+    torch.cuda.empty_cache()
