@@ -496,6 +496,8 @@ public:
         c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
         const hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
         const Tensor m = moments.to(at::kDouble).contiguous();
+        TORCH_CHECK(m.dim() == 2 && m.size(1) == TL_NMOM && n_lens >= 1 && m.size(0) % n_lens == 0,
+                    "unsup_loss: moments must be [n_lens * F, TL_NMOM]");
         Tensor ns;
         if (n_seq && n_seq->defined()) {
             ns = n_seq->to(dev, at::kDouble).reshape({-1}).contiguous();
