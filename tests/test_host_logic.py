@@ -185,6 +185,32 @@ def test_cabi_library_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.tl_problem) == dll.tl_problem_size() == 248
 
 
+def test_new_entry_points_refuse_bad_arguments_before_touching_a_device():
+    """tl_unsup_loss / tl_unsup_loss_bwd / tl_aim_fan check their arguments first: TL_EINVAL and a message, no HIP call
+    (so this runs without a GPU); the scan map of the penalty walk-back is part of tl_workspace_bytes."""
+    import ctypes as C
+    from torchoptics_amd import _lib
+    dll = _lib.lib()
+    one = C.c_void_p(8)                                   # any non-NULL pointer: never dereferenced on these paths
+    EINVAL = -1                                           # TL_EINVAL (include/tl_trace.h)
+    assert dll.tl_unsup_loss(0, 0, 3, 100.0, one, None, 7.0, 0.2, one, one, one, one, None) == EINVAL
+    assert dll.tl_unsup_loss(0, 2, 3, 100.0, one, None, 0.0, 0.2, one, one, one, one, None) == EINVAL   # no n_sequence at all
+    assert dll.tl_unsup_loss(0, 2, 3, 100.0, one, None, 7.0, 0.2, None, one, one, one, None) == EINVAL
+    assert b"tl_unsup_loss" in dll.tl_last_error()
+    assert dll.tl_unsup_loss_bwd(0, 2, 3, one, None, None, None, 1, None, 7.0, 0.2, one, None) == EINVAL   # no upstream gradient
+    assert dll.tl_unsup_loss_bwd(0, 2, 3, one, one, None, None, 2, None, 7.0, 0.2, one, None) == EINVAL    # stride 0 or 1
+    assert dll.tl_aim_fan(0, 1, 3, 3, 0, one, one, one, one, one, one, one, one, None) == EINVAL
+    assert dll.tl_aim_fan(0, 1, 3, 3, 64, one, None, one, one, one, one, one, one, None) == EINVAL
+    assert dll.tl_aim_fan(0, 30000, 3, 3, 64, one, one, one, one, one, one, one, one, None) == EINVAL      # grid rows
+    p = _lib.tl_problem()
+    p.F, p.W, p.S = 1, 1, 11
+    p.P = 1 << 20
+    small = dll.tl_workspace_bytes(C.byref(p))
+    p.P = 1 << 24
+    big = dll.tl_workspace_bytes(C.byref(p))
+    assert big - small >= ((1 << 24) - (1 << 20)) // 256 * 4          # one byte per chunk and wave of the block
+
+
 def test_gradient_free_conversions_are_memoised_safely():
     """lens_modeling caches the padding of constant nd / v and their dispersion (an optimisation loop rebuilds
     the same Lens every step).  The cache must notice new data at a recycled address, in-place updates of the
