@@ -47,7 +47,7 @@ def _same(a, b, what=""):
         assert torch.equal(p, q), (what, i)
 
 
-CASES = ["plain", "asph", "penalty", "penalty_stacks", "opd", "input_grads", "noback", "x_moments"]
+CASES = ["plain", "asph", "penalty", "penalty_stacks", "opd", "input_grads", "noback", "x_moments", "rms_and_moments"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -79,7 +79,7 @@ def test_cpp_and_python_host_chains_agree_bit_for_bit(ta, case):
             nidx = torch.stack(n, dim=-1).requires_grad_(True)
             kw.update(n_index=nidx, want_opd=True)
             extra_leaves.append(nidx)
-        if case == "x_moments":
+        if case in ("x_moments", "rms_and_moments"):
             kw.update(x_moments=True)
         x_in, y_in = ins[0], ins[1]
         if case == "input_grads":
@@ -89,6 +89,10 @@ def test_cpp_and_python_host_chains_agree_bit_for_bit(ta, case):
             extra_leaves += [x_in, y_in]
         out = ta.trace_skew(x_in, y_in, lv[0], ins[3], lv[1], lv[2], lv[3], lv[4], mask, agg, allow, **kw)
         loss = rt.compute_rms_spot_xy(out[0], out[1], out[4]) if case == "x_moments" else ta.compute_rms2d(out[0], out[1], out[4])
+        if case == "rms_and_moments":
+            # the spot metric fused into the C++ trace node AND a second loss on the moments themselves: their two
+            # gradients meet inside that node's backward (autograd's accumulation under the Python chain)
+            loss = loss + 0.5 * rt.compute_rms_spot_xy(out[0], out[1], out[4]) + 2.0 * ta.compute_rms2d(out[0], out[1], out[4])
         loss = loss + 1e-3 * (out[0] * out[2]).sum()                                    # dense seeds on x and cx as well
         if agg:
             loss = loss + 0.2 * rt.penalty_sum(out[6], S)

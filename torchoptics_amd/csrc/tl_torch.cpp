@@ -182,7 +182,7 @@ thread_local bool g_last_use_inv = false;
 
 // flag bits of the int argument of TraceFn (kept in one int: every extra non-tensor argument of a custom function is
 // one more slot in the gradient list)
-enum { kAllowBack = 1, kWantRays = 2, kWantOpd = 4, kAggregate = 8, kWantStacks = 16, kMomentsX = 32, kInverse = 64 };
+enum { kAllowBack = 1, kWantRays = 2, kWantOpd = 4, kAggregate = 8, kWantStacks = 16, kMomentsX = 32, kInverse = 64, kFuseRms = 128 };
 
 class TraceFn : public torch::autograd::Function<TraceFn> {
 public:
@@ -281,10 +281,22 @@ public:
                                (double *)moments.data_ptr(), ws.data_ptr(), (size_t)ws.numel(), (void *)st),
                   "tl_trace_fwd");
         }
+        // kFuseRms: compute_rms2d of these rays (every lens of the batch; n = P W rays per field) as a tenth output of THIS
+        // node -- one tl_spot_rms launch here instead of a second extension call and a second autograd node for the loss
+        // every caller of the spot metric forms next (ray_tracing.compute_rms2d picks it up)
+        Tensor rms, d_rms;
+        if ((flags & kFuseRms) && want_rays && P > 0) {
+            rms = B == 1 ? at::empty({}, fopt) : at::empty({B}, fopt);
+            d_rms = at::empty_like(moments);
+            check(tl_spot_rms(dev.index(), (int32_t)B, (int32_t)F, (double)(P * W), (const double *)moments.data_ptr(),
+                              (float *)rms.data_ptr(), (double *)d_rms.data_ptr(), (void *)st),
+                  "tl_spot_rms");
+        }
         const bool inv = use_inv;
         ctx->save_for_backward({n.x_e, n.y_e, n.z, n.cx, n.cy, n.c, n.t, n.mu, n.mask, n.kappa, n.poly, n.kind,
                                 inv ? fp[0] : Tensor(), inv ? fp[1] : Tensor(), inv ? fp[2] : Tensor(), inv ? fp[3] : Tensor(),
-                                inv ? bp[0] : Tensor(), inv ? moments : Tensor(), want_opd ? n.n_index : Tensor(), hits, cond});
+                                inv ? bp[0] : Tensor(), inv ? moments : Tensor(), want_opd ? n.n_index : Tensor(), hits, cond,
+                                d_rms});
         // needs_input_grad() of the backward counts the tensor arguments that are PRESENT: an absent optional has no edge
         {
             int64_t e = 9;
@@ -316,9 +328,11 @@ public:
         }
         Tensor opd_out = want_opd ? opd.permute({0, 1, 3, 2}) : at::empty({0}, fopt);
         Tensor stk_out = stacks.defined() ? stacks.permute({0, 1, 2, 3, 5, 4}) : at::empty({0}, fopt);
+        Tensor rms_out = rms.defined() ? rms : at::empty({0}, fopt);
         if (want_opd) ctx->mark_non_differentiable({ok, back, stk_out});
         else ctx->mark_non_differentiable({ok, back, stk_out, opd_out});
-        return {xo, yo, cxo, cyo, ok, back, moments, opd_out, stk_out};
+        if (!rms.defined()) ctx->mark_non_differentiable({rms_out});
+        return {xo, yo, cxo, cyo, ok, back, moments, opd_out, stk_out, rms_out};
     }
 
     static variable_list backward(AutogradContext *ctx, variable_list g)
@@ -329,7 +343,7 @@ public:
         n.mask = sv[8]; n.kappa = sv[9]; n.poly = sv[10]; n.kind = sv[11];
         const Tensor fx = sv[12], fy = sv[13], fcx = sv[14], fcy = sv[15], fok = sv[16], fmom = sv[17];
         n.n_index = sv[18];
-        const Tensor hits = sv[19], cond = sv[20];
+        const Tensor hits = sv[19], cond = sv[20], d_rms = sv[21];
         n.B = n.x_e.size(0); n.F = n.x_e.size(1); n.P = n.x_e.size(2); n.W = n.x_e.size(3); n.S = n.c.size(-1);
         const int64_t B = n.B, F = n.F, P = n.P, W = n.W, S = n.S;
         const int64_t flags = ctx->saved_data["flags"].toInt();
@@ -337,6 +351,12 @@ public:
         const bool allow_back = flags & kAllowBack, aggregate = flags & kAggregate;
         variable_list out(16);
         Tensor gx = g[0], gy = g[1], gcx = g[2], gcy = g[3], gmom = g[6], gopd = g[7];
+        if (g.size() > 9 && g[9].defined() && d_rms.defined()) {
+            // the fused spot metric: d rms / d moments times its upstream gradient (SpotRmsFn's backward), added to whatever
+            // reached the moments directly -- what autograd's accumulation of the two would give
+            const Tensor via_rms = B == 1 ? d_rms * g[9] : (d_rms.view({B, -1, TL_NMOM}) * g[9].view({-1, 1, 1})).view_as(d_rms);
+            gmom = gmom.defined() ? gmom + via_rms : via_rms;
+        }
         if (gopd.defined() && (!n.n_index.defined() || gopd.numel() == 0)) gopd = Tensor();
         if (!gx.defined() && !gy.defined() && !gcx.defined() && !gcy.defined() && !gmom.defined() && !gopd.defined()) return out;
         const bool asph = n.kind.defined();
@@ -585,5 +605,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("abi_version", [] { return tl_version(); });
     m.attr("ALLOW_BACK") = (int)kAllowBack; m.attr("WANT_RAYS") = (int)kWantRays; m.attr("WANT_OPD") = (int)kWantOpd;
     m.attr("AGGREGATE") = (int)kAggregate; m.attr("WANT_STACKS") = (int)kWantStacks; m.attr("MOMENTS_X") = (int)kMomentsX;
-    m.attr("INVERSE") = (int)kInverse;
+    m.attr("INVERSE") = (int)kInverse; m.attr("FUSE_RMS") = (int)kFuseRms;
 }

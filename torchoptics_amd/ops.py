@@ -564,13 +564,21 @@ class PupilPositionFunction(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------ entry points of the host chain
+def _dist_initialized() -> bool:
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
 def trace_cpp(ext, x, y, z, cx, cy, c, t, mu, mask, kappa, poly, kind, n_index, allow_back, mode, want_rays, want_opd,
               aggregate, want_stacks, moments_x):
     """The trace through the C++ host extension: the arguments exactly as trace_skew received them (their broadcast
     shapes are normalised in C++).  Returns (the nine outputs of TraceFunction, use_inv)."""
     flags = ((ext.ALLOW_BACK if allow_back else 0) | (ext.WANT_RAYS if want_rays else 0) | (ext.WANT_OPD if want_opd else 0)
              | (ext.AGGREGATE if aggregate else 0) | (ext.WANT_STACKS if want_stacks else 0)
-             | (ext.MOMENTS_X if moments_x else 0) | (ext.INVERSE if _bwd_algo == "inverse" else 0))
+             | (ext.MOMENTS_X if moments_x else 0) | (ext.INVERSE if _bwd_algo == "inverse" else 0)
+             # the spot metric of the traced rays as an output of the same node (ray_tracing.compute_rms2d picks it up);
+             # not when the pupil is sharded over ranks: the moments are summed across them first
+             # (nor with the penalty term: those callers take the whole loss_dict from the moments, unsup_loss below)
+             | (ext.FUSE_RMS if (want_rays and not aggregate and hasattr(ext, "FUSE_RMS") and not _dist_initialized()) else 0))
     out = ext.trace(x, y, z, cx, cy, c, t, mu, mask, kappa, poly, kind, n_index, flags, _MODES[mode], ASPH_HIT_SLOTS)
     return out, ext.last_use_inv()
 

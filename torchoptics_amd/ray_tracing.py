@@ -328,11 +328,12 @@ def trace_skew(x, y, z, cx, cy, c, t, mu, mask, aggregate=False, allow_backward_
 
 def _trace_result(out, use_inv, want_rays, want_opd, aggregate, x_moments, n_pw, B):
     """The tuple trace_skew returns, from the nine outputs of the trace function."""
-    xo, yo, cxo, cyo, ok, back, moments, opd, stk = out
+    xo, yo, cxo, cyo, ok, back, moments, opd, stk = out[:9]
+    rms = out[9] if len(out) > 9 and out[9].numel() > 0 else None      # C++ host chain: the spot metric, fused into the trace node
     if want_rays:
         # remember which moments belong to these rays (checked by identity + version in compute_rms2d):
-        # [B*F, TL_NMOM], lens-major
-        yo._tl_spot = (moments, ok, yo._version, n_pw, bool(x_moments))
+        # [B*F, TL_NMOM], lens-major; and their spot metric when the trace node computed it already
+        yo._tl_spot = (moments, ok, yo._version, n_pw, bool(x_moments), rms)
         xo._tl_use_inv = bool(use_inv)                 # which backward algorithm this trace will take (ops.used_walk_back)
         res = (xo, yo, cxo, cyo, ok, back)
         if want_opd:
@@ -482,6 +483,8 @@ def compute_rms2d(x, y, ray_ok, group=None, n_per_field: Optional[int] = None):
     tag = getattr(y, "_tl_spot", None)
     if tag is not None and tag[1] is ray_ok and tag[2] == y._version:
         moments, n_local = tag[0], tag[3]
+        if group is None and len(tag) > 5 and tag[5] is not None and n_per_field in (None, n_local) and y.dtype == torch.float32:
+            return tag[5] if y.shape[0] == 1 else tag[5][0]        # computed by the trace node itself (one launch, one node)
         if y.shape[0] > 1:                       # the reference reads sample 0 only (:695,699)
             moments = moments[: y.shape[1]]
     else:
@@ -507,6 +510,8 @@ def compute_rms2d_batch(x, y, ray_ok):
     tag = getattr(y, "_tl_spot", None)
     if tag is not None and tag[1] is ray_ok and tag[2] == y._version:
         moments, n_local = tag[0], tag[3]
+        if len(tag) > 5 and tag[5] is not None and y.dtype == torch.float32:
+            return tag[5].reshape(B)                               # computed by the trace node itself
     else:
         fold = lambda a: None if a is None else a.reshape(1, B * F, a.shape[2], a.shape[3])      # noqa: E731
         moments = ops.SpotMomentsFunction.apply(fold(x), fold(y), fold(ray_ok))
